@@ -1,0 +1,170 @@
+/* reloc.h -- C-ABI of libreloc_hip.so, the MI355X (gfx950) visual-relocalization library.
+ *
+ * The reference (vbronetskyi/nclt-slam-project) has no FFI for this path: its boundary is the
+ * Python `cv2` API at the call sites listed below, with OpenCV's CPU code underneath.  This
+ * header DEFINES the C-ABI that replaces that native layer; every entry point cites the
+ * reference call it serves (paths relative to simulation/isaac/ in the reference tree):
+ *   M = scripts/common/visual_landmark_matcher.py     R = scripts/common/visual_landmark_recorder.py
+ *   G = experiments/63_global_reloc/scripts/visual_landmark_matcher.py
+ *   S = experiments/55_visual_teach_repeat/scripts/checkpoint_a_selftest.py
+ * The Python binding a maintainer adds is shown in INTEGRATION.md; the shipped one is
+ * nclt-slam-project_amd/_native.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no framework types.
+ *   - every function returns 0 on success or a negative RELOC_E_* code; reloc_last_error()
+ *     gives the message of the calling thread's last failure.
+ *   - a reloc_ctx owns one HIP stream, its scratch buffers and (optionally) one uploaded
+ *     landmark database.  A ctx is not thread-safe; any number of ctxs may coexist.
+ *   - functions without a suffix take HOST pointers, run synchronously and return results in
+ *     caller-allocated host memory (what the cv2-shaped Python layer needs).
+ *   - functions ending in _dev take DEVICE pointers (hipMalloc / reloc_dev_alloc / a torch
+ *     tensor's data_ptr()), enqueue on the ctx stream and return without synchronising.
+ *   - there is NO CPU fallback: every compute entry point fails with RELOC_E_NODEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef RELOC_H
+#define RELOC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELOC_OK            0
+#define RELOC_E_ARG        (-1)   /* bad argument (cv2.error in the Python layer)          */
+#define RELOC_E_NODEVICE   (-2)   /* no usable HIP device                                  */
+#define RELOC_E_HIP        (-3)   /* HIP runtime error, see reloc_last_error()             */
+#define RELOC_E_CAPACITY   (-4)   /* input exceeds a ctx capacity                          */
+#define RELOC_E_STATE      (-5)   /* call needs state that is missing (e.g. no database)   */
+
+#define RELOC_ORDER_BGR 0
+#define RELOC_ORDER_RGB 1
+
+/* outcome codes of reloc_tick, one per CSV outcome string of M:308,313,383,395,428 */
+#define RELOC_OUT_PUBLISHED        0
+#define RELOC_OUT_NO_FEATURES      1   /* curr_no_features  */
+#define RELOC_OUT_NO_CANDIDATES    2   /* no_candidates     */
+#define RELOC_OUT_NO_PNP_ACCEPT    3   /* no_pnp_accept     */
+#define RELOC_OUT_CONSISTENCY_FAIL 4   /* consistency_fail_ */
+
+typedef struct reloc_ctx reloc_ctx;
+
+/* ---- lifetime, errors, plumbing ----------------------------------------------------------- */
+const char *reloc_last_error(void);
+int  reloc_device_count(void);
+/* max_w/max_h: largest frame; max_feat: largest keypoint / descriptor count per frame. */
+reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat);
+void reloc_destroy(reloc_ctx *ctx);
+/* Use an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL
+ * restores the ctx's own stream. */
+int  reloc_set_stream(reloc_ctx *ctx, void *hip_stream);
+int  reloc_sync(reloc_ctx *ctx);
+void *reloc_dev_alloc(reloc_ctx *ctx, int64_t bytes);
+int  reloc_dev_free(reloc_ctx *ctx, void *p);
+int  reloc_h2d(reloc_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);   /* async */
+int  reloc_d2h(reloc_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);   /* async */
+/* HIP-event stopwatch on the ctx stream: begin(); ...launches...; end() -> ms (synchronises). */
+int  reloc_timer_begin(reloc_ctx *ctx);
+int  reloc_timer_end(reloc_ctx *ctx, float *ms);
+/* Per-kernel stopwatch: when enabled, the dominant kernels are bracketed by HIP events on the
+ * ctx stream; get() synchronises and returns total ms and launch count of kernel `which`. */
+#define RELOC_PROF_DB_SCAN  0
+#define RELOC_PROF_MATRIX   1
+#define RELOC_PROF_ORB      2
+#define RELOC_PROF_PNP      3
+#define RELOC_PROF_N        4
+int  reloc_profile_enable(reloc_ctx *ctx, int on);
+int  reloc_profile_get(reloc_ctx *ctx, int which, float *total_ms, int32_t *launches);
+
+/* ---- ORB front end ------------------------------------------------------------------------ */
+/* cv2.cvtColor(img, COLOR_BGR2GRAY)                                         M:305  R:240  S:44 */
+int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, int stride, int order,
+                  uint8_t *gray);
+/* cv2.ORB_create(nfeatures).detectAndCompute(gray, None)                    M:306  R:241  S:48
+ * Outputs hold up to the ctx's max_feat rows; *n_out = rows written.  Keypoints are level-major,
+ * raster order inside a level.  xy = KeyPoint.pt (level-0 pixels), octave = pyramid level. */
+int reloc_orb_detect_compute(reloc_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                             int nfeatures, float *xy, float *size, float *angle, float *response,
+                             int32_t *octave, uint8_t *desc, int32_t *n_out);
+/* Same from a 3-channel frame already in device memory (gray conversion fused in front);
+ * results stay in ctx-owned device buffers (see reloc_frame_*).  Enqueue only. */
+int reloc_orb_frame_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int stride, int order,
+                        int nfeatures);
+/* Device views of the last frame's features (valid until the next frame call). */
+const uint8_t *reloc_frame_desc_dev(reloc_ctx *ctx);      /* max_feat x 32 u8                  */
+const float   *reloc_frame_xy_dev(reloc_ctx *ctx);        /* max_feat x 2 f32                  */
+const int32_t *reloc_frame_count_dev(reloc_ctx *ctx);     /* 1 x i32: number of keypoints      */
+/* Debug/parity taps: copy intermediate planes of the last frame to host.  level in [0, 8).
+ * what: 0 = pyramid level, 1 = blurred level, 2 = NMS-kept FAST score map. */
+int reloc_frame_debug_plane(reloc_ctx *ctx, int what, int level, uint8_t *out, int32_t *w, int32_t *h);
+
+/* ---- 256-bit Hamming matching --------------------------------------------------------------- */
+/* cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(q, t)                  M:211,327  G:337
+ * Mutual nearest neighbours, lowest index on ties, sorted by queryIdx.  Outputs sized min(nq,nt). */
+int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                       int32_t *qidx, int32_t *tidx, int32_t *dist, int32_t *n_out);
+/* cv2.BFMatcher(NORM_HAMMING, crossCheck=False).knnMatch(q, t, k=2)         S:46,68
+ * idx/dist are nq x 2; a missing second neighbour is (-1, -1). */
+int reloc_match_knn2(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                     int32_t *idx, int32_t *dist);
+/* landmarks.pkl -> packed device arena (R:290-297, M:179-187).  desc: T x 32; pts3d: T x 3
+ * (keypoints_3d_cam); offsets: L+1 row offsets; poses: L x 7 camera pose (x y z qx qy qz qw).
+ * Replaces any previously uploaded database. */
+int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const int64_t *offsets,
+                    const double *poses, int64_t n_records);
+int64_t reloc_db_records(reloc_ctx *ctx);
+int64_t reloc_db_rows(reloc_ctx *ctx);
+/* Whole-database scan of G:329-344: per record, the number of mutual matches between the
+ * record's descriptors (query) and the current frame's descriptors (train).  cur: n_cur x 32. */
+int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts);
+int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, const int32_t *n_cur_dev,
+                              int n_cur_max, int32_t *counts_dev);
+/* All-pairs u16 distance matrix (loop-closure sweep shape; no reference counterpart,
+ * BASELINE.json config 5): out[i * nb + j] = hamming(a_i, b_j). */
+int reloc_hamming_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,
+                         uint16_t *out);
+int reloc_hamming_matrix_dev(reloc_ctx *ctx, const uint8_t *a_dev, int64_t na, const uint8_t *b_dev,
+                             int64_t nb, uint16_t *out_dev);
+
+/* ---- PnP ------------------------------------------------------------------------------------ */
+/* Hypothesis scorer inside cv2.solvePnPRansac (M:342-346): inlier count of H poses
+ * (R row-major 9 + t 3 doubles each) over m correspondences; K4 = fx fy cx cy. */
+int reloc_pnp_score(reloc_ctx *ctx, const float *obj, const float *img, int m, const double *Rt, int H,
+                    const double K4[4], float thr_px, int32_t *inlier_count, uint8_t *mask);
+/* cv2.solvePnPRansac(obj, img, K, DIST, iterationsCount=, reprojectionError=, flags=ITERATIVE)
+ *                                                                            M:342-346  S:78-82
+ * inliers must hold m entries. */
+int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *img, int m, const double K4[4],
+                     int iters, float thr_px, double conf, uint64_t seed, double rvec[3],
+                     double tvec[3], int32_t *inliers, int32_t *n_inl, int32_t *ok);
+
+/* ---- fused tick ----------------------------------------------------------------------------- */
+/* One repeat tick against the uploaded database (M:281-433 with G:315-344's whole-database
+ * candidate search when global_reloc != 0): gray -> ORB -> candidates -> mutual match ->
+ * PnP-RANSAC -> reprojection gate -> pose compose -> best by inliers -> consistency gate.
+ * base_pose: x y z qx qy qz qw of base_link (the /tmp/isaac_pose.txt line).
+ * Outputs: anchor_pose[7] (base_link in the teach map), n_inl, reproj (px), lm_idx, outcome,
+ * n_candidates.  Host pointers; synchronous. */
+int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int order, const double base_pose[7],
+               int global_reloc, uint64_t seed, double anchor_pose[7], int32_t *n_inl, float *reproj,
+               int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
+/* Same with the frame already resident in device memory; enqueues everything and leaves the
+ * result in a ctx-owned device record readable with reloc_tick_result(). */
+int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order,
+                   const double base_pose[7], int global_reloc, uint64_t seed);
+int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
+                      int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
+/* Sharded database (one rank per GPU): per-record mutual-match counts are local; the caller
+ * exchanges the per-shard top-k (count, global id) lists and tells each rank which of ITS
+ * records made the global top-k.  These two calls split reloc_tick_dev at that exchange. */
+int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order,
+                        int32_t *topk_ids_dev, int32_t *topk_counts_dev, int k);
+int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand,
+                         const double base_pose[7], int check_consistency, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELOC_H */

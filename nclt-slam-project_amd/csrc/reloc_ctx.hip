@@ -1,0 +1,279 @@
+// reloc_ctx.hip -- context lifetime, error reporting, stream/event plumbing of libreloc_hip.so.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "reloc_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void reloc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+RELOC_API const char *reloc_last_error(void) { return g_err; }
+
+RELOC_API int reloc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <typename T>
+static int dalloc(T **p, int64_t count)
+{
+    HIP_TRY(hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+    return 0;
+}
+
+static int ctx_alloc(reloc_ctx *c)
+{
+    int rc = 0;
+    const int64_t mf = c->max_feat;
+    // pyramid geometry upper bound: sum over levels of stride*h with stride <= w+64 rounded
+    int64_t pyr = 0;
+    for (int l = 0; l < NLEV; ++l) {
+        double s = pow(RELOC_ORB_SCALE_FACTOR, (double)l);
+        int64_t w = (int64_t)(c->max_w / s) + 2, h = (int64_t)(c->max_h / s) + 2;
+        pyr += ((w + 63) / 64 * 64) * h + 256;
+    }
+    c->pyr_bytes = pyr;
+    rc |= dalloc(&c->pyr, pyr);
+    rc |= dalloc(&c->blur, pyr);
+    rc |= dalloc(&c->nms, pyr);
+    rc |= dalloc(&c->rz_tab, (int64_t)NLEV * 2 * 2 * (c->max_w > c->max_h ? c->max_w : c->max_h));
+    rc |= dalloc(&c->hist, NLEV * 256);
+    rc |= dalloc(&c->cand_cnt, NLEV);
+    rc |= dalloc(&c->cand_key, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
+    rc |= dalloc(&c->cand_resp, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
+    rc |= dalloc(&c->kp_cnt, NLEV + 1);
+    rc |= dalloc(&c->kp_key, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
+    rc |= dalloc(&c->kp_resp, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
+    rc |= dalloc(&c->f_xy, mf * 2);
+    rc |= dalloc(&c->f_size, mf);
+    rc |= dalloc(&c->f_angle, mf);
+    rc |= dalloc(&c->f_resp, mf);
+    rc |= dalloc(&c->f_oct, mf);
+    rc |= dalloc(&c->f_desc, mf * 32);
+    rc |= dalloc(&c->f_count, 1);
+    rc |= dalloc(&c->frame_img, (int64_t)c->max_w * c->max_h * 3);
+    rc |= dalloc((OrbLevel **)&c->orb_const, NLEV);
+    rc |= dalloc(&c->cand_ids, MAX_CAND);
+    rc |= dalloc(&c->cand_n, 1);
+    rc |= dalloc(&c->m_qidx, (int64_t)MAX_CAND * MAX_REC_ROWS);
+    rc |= dalloc(&c->m_tidx, (int64_t)MAX_CAND * MAX_REC_ROWS);
+    rc |= dalloc(&c->m_dist, (int64_t)MAX_CAND * MAX_REC_ROWS);
+    rc |= dalloc(&c->m_n, MAX_CAND);
+    rc |= dalloc(&c->p_obj, (int64_t)MAX_CAND * MAX_REC_ROWS * 3);
+    rc |= dalloc(&c->p_img, (int64_t)MAX_CAND * MAX_REC_ROWS * 2);
+    rc |= dalloc(&c->p_Rt, (int64_t)MAX_CAND * MAX_HYP * 12);
+    rc |= dalloc(&c->p_cnt, (int64_t)MAX_CAND * MAX_HYP);
+    rc |= dalloc(&c->p_inl, (int64_t)MAX_CAND * MAX_REC_ROWS);
+    rc |= dalloc(&c->p_out, MAX_CAND);
+    rc |= dalloc(&c->tick_res, 1);
+    rc |= dalloc(&c->tick_pose, 8);
+    return rc;
+}
+
+RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        reloc_set_error("no HIP device available (libreloc_hip has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n || max_w < 64 || max_h < 64 || max_feat < 64) {
+        reloc_set_error("reloc_create: bad arguments (device %d of %d, %dx%d, max_feat %d)", device, n,
+                        max_w, max_h, max_feat);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        reloc_set_error("hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    reloc_ctx *c = new reloc_ctx();
+    c->device = device;
+    c->max_w = max_w;
+    c->max_h = max_h;
+    c->max_feat = max_feat;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+        reloc_set_error("stream/event creation failed");
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    if (ctx_alloc(c) != 0) {
+        reloc_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+RELOC_API void reloc_destroy(reloc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
+                    c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
+                    c->f_desc, c->f_count, c->frame_img, c->orb_const, c->db_desc, c->db_pts3d, c->db_off,
+                    c->db_pose, c->db_xy_heading, c->db_counts, c->cand_ids, c->cand_n, c->m_qidx,
+                    c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
+                    c->p_out, c->tick_res, c->tick_pose};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < 8; ++i)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (int k = 0; k < RELOC_PROF_N; ++k)
+        if (c->prof[k].init)
+            for (int i = 0; i < 64; ++i) {
+                (void)hipEventDestroy(c->prof[k].a[i]);
+                (void)hipEventDestroy(c->prof[k].b[i]);
+            }
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+RELOC_API int reloc_set_stream(reloc_ctx *c, void *hip_stream)
+{
+    ARG_CHECK(c, "ctx is NULL");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_sync(reloc_ctx *c)
+{
+    ARG_CHECK(c, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RELOC_OK;
+}
+
+RELOC_API void *reloc_dev_alloc(reloc_ctx *c, int64_t bytes)
+{
+    if (!c || bytes < 0) { reloc_set_error("reloc_dev_alloc: bad arguments"); return nullptr; }
+    void *p = nullptr;
+    (void)hipSetDevice(c->device);
+    if (hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 1)) != hipSuccess) {
+        reloc_set_error("hipMalloc(%lld) failed", (long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+RELOC_API int reloc_dev_free(reloc_ctx *c, void *p)
+{
+    ARG_CHECK(c, "ctx is NULL");
+    if (p) HIP_TRY(hipFree(p));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_h2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    ARG_CHECK(c && dst && src && bytes >= 0, "reloc_h2d");
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_d2h(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    ARG_CHECK(c && dst && src && bytes >= 0, "reloc_d2h");
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_timer_begin(reloc_ctx *c)
+{
+    ARG_CHECK(c, "ctx is NULL");
+    HIP_TRY(hipEventRecord(c->t0, c->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_timer_end(reloc_ctx *c, float *ms)
+{
+    ARG_CHECK(c && ms, "reloc_timer_end");
+    HIP_TRY(hipEventRecord(c->t1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->t1));
+    HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
+    return RELOC_OK;
+}
+
+int reloc_scratch(reloc_ctx *c, int slot, int64_t bytes, void **out)
+{
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipFree(c->scratch[slot]));
+            c->scratch[slot] = nullptr;
+            c->scratch_bytes[slot] = 0;
+        }
+        int64_t cap = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(&c->scratch[slot], (size_t)cap));
+        c->scratch_bytes[slot] = cap;
+    }
+    *out = c->scratch[slot];
+    return RELOC_OK;
+}
+
+// ---- per-kernel HIP-event stopwatch ----------------------------------------------------------
+static void prof_flush(reloc_ctx *c, int which)
+{
+    auto &p = c->prof[which];
+    for (int i = 0; i < p.n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b[i]) == hipSuccess && hipEventElapsedTime(&ms, p.a[i], p.b[i]) == hipSuccess) {
+            p.total += ms;
+            p.launches += 1;
+        }
+    }
+    p.n = 0;
+}
+
+void reloc_prof_begin(reloc_ctx *c, int which)
+{
+    if (!c->prof_on) return;
+    auto &p = c->prof[which];
+    if (!p.init) {
+        for (int i = 0; i < 64; ++i) { (void)hipEventCreate(&p.a[i]); (void)hipEventCreate(&p.b[i]); }
+        p.init = true;
+    }
+    if (p.n == 64) prof_flush(c, which);
+    (void)hipEventRecord(p.a[p.n], c->stream);
+}
+
+void reloc_prof_end(reloc_ctx *c, int which)
+{
+    if (!c->prof_on) return;
+    auto &p = c->prof[which];
+    (void)hipEventRecord(p.b[p.n], c->stream);
+    p.n += 1;
+}
+
+RELOC_API int reloc_profile_enable(reloc_ctx *c, int on)
+{
+    ARG_CHECK(c, "ctx is NULL");
+    for (int k = 0; k < RELOC_PROF_N; ++k) {
+        prof_flush(c, k);
+        c->prof[k].total = 0.f;
+        c->prof[k].launches = 0;
+    }
+    c->prof_on = on;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_profile_get(reloc_ctx *c, int which, float *total_ms, int32_t *launches)
+{
+    ARG_CHECK(c && which >= 0 && which < RELOC_PROF_N && total_ms && launches, "reloc_profile_get");
+    prof_flush(c, which);
+    *total_ms = c->prof[which].total;
+    *launches = c->prof[which].launches;
+    return RELOC_OK;
+}

@@ -1,0 +1,147 @@
+// reloc_internal.h -- shared declarations of libreloc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/reloc.h"
+#include "../../include/reloc_spec.h"
+
+#define RELOC_API extern "C" __attribute__((visibility("default")))
+
+void reloc_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            reloc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                     \
+            return RELOC_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define ARG_CHECK(cond, msg)                                 \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            reloc_set_error("bad argument: %s", msg);        \
+            return RELOC_E_ARG;                              \
+        }                                                    \
+    } while (0)
+
+constexpr int NLEV = RELOC_ORB_NLEVELS;
+constexpr int MAX_REC_ROWS = 4096;   // largest record (teach rows) the fused scan accepts
+constexpr int MAX_CAND = 32;         // PnP candidates per tick (5 local / 25 global)
+constexpr int MAX_HYP = 256;         // RANSAC hypotheses per candidate
+
+struct OrbLevel {
+    int w, h;          // level size
+    int stride;        // row stride in bytes (multiple of 64)
+    int64_t off;       // byte offset of the level inside a pyramid buffer
+    float scale;
+    int quota;
+};
+
+// Result record of one tick (device resident, copied out by reloc_tick_result)
+struct TickResult {
+    double anchor_pose[7];
+    double reproj;
+    int32_t n_inl;
+    int32_t lm_idx;
+    int32_t outcome;
+    int32_t n_candidates;
+    int32_t n_features;
+    int32_t pad;
+};
+
+// Per-candidate PnP output
+struct PnpOut {
+    double Rt[12];       // refined pose (teach cam -> current cam)
+    double rvec[3];
+    double reproj_mean;  // mean inlier reprojection error (px) under the refined pose
+    int32_t ok;
+    int32_t n_inl;
+    int32_t best_h;
+    int32_t n_matches;
+};
+
+struct reloc_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, max_feat = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int num_cu = 256;
+
+    // profiling
+    int prof_on = 0;
+    struct ProfSlot { hipEvent_t a[64], b[64]; int n = 0; float total = 0.f; int launches = 0; bool init = false; } prof[RELOC_PROF_N];
+
+    // generic scratch (grown on demand by host-pointer entry points)
+    void *scratch[8] = {};
+    int64_t scratch_bytes[8] = {};
+
+    // ---- ORB state ----
+    int orb_w = 0, orb_h = 0, orb_nfeat = 0;     // geometry the tables below were built for
+    OrbLevel lev[NLEV];
+    int64_t pyr_bytes = 0;
+    uint8_t *pyr = nullptr;        // pyramid levels
+    uint8_t *blur = nullptr;       // blurred levels
+    uint8_t *nms = nullptr;        // NMS-kept score maps (debug tap + stage-1 source)
+    int32_t *rz_tab = nullptr;     // resize tables (device)
+    int32_t *hist = nullptr;       // NLEV x 256 score histograms
+    int32_t *cand_cnt = nullptr;   // NLEV counters (stage-1 list sizes)
+    uint32_t *cand_key = nullptr;  // NLEV x STAGE1_CAP packed (y<<16|x)
+    float *cand_resp = nullptr;    // NLEV x STAGE1_CAP Harris responses
+    int32_t *kp_cnt = nullptr;     // NLEV kept counts + [NLEV] total
+    uint32_t *kp_key = nullptr;    // NLEV x STAGE1_CAP kept keypoints (raster order per level)
+    float *kp_resp = nullptr;
+    // frame feature outputs (max_feat rows)
+    float *f_xy = nullptr, *f_size = nullptr, *f_angle = nullptr, *f_resp = nullptr;
+    int32_t *f_oct = nullptr;
+    uint8_t *f_desc = nullptr;
+    int32_t *f_count = nullptr;
+    uint8_t *frame_gray = nullptr; // unused when level 0 is written directly
+    uint8_t *frame_img = nullptr;  // staging for host frames (max_w*max_h*3)
+    void *orb_const = nullptr;     // device copy of level table
+
+    // ---- database ----
+    int64_t db_records = 0, db_rows = 0;
+    int db_max_rows = 0;
+    uint8_t *db_desc = nullptr;
+    float *db_pts3d = nullptr;
+    int64_t *db_off = nullptr;
+    double *db_pose = nullptr;
+    double *db_xy_heading = nullptr; // L x 3 (x, y, heading) for candidate selection
+    int32_t *db_counts = nullptr;    // L per-record mutual counts
+
+    // ---- tick state ----
+    int32_t *cand_ids = nullptr;     // MAX_CAND
+    int32_t *cand_n = nullptr;       // 1
+    int32_t *m_qidx = nullptr, *m_tidx = nullptr, *m_dist = nullptr, *m_n = nullptr; // MAX_CAND x MAX_REC_ROWS
+    float *p_obj = nullptr, *p_img = nullptr;     // MAX_CAND x MAX_REC_ROWS x {3,2}
+    double *p_Rt = nullptr;          // MAX_CAND x MAX_HYP x 12
+    int32_t *p_cnt = nullptr;        // MAX_CAND x MAX_HYP
+    int32_t *p_inl = nullptr;        // MAX_CAND x MAX_REC_ROWS
+    PnpOut *p_out = nullptr;         // MAX_CAND
+    TickResult *tick_res = nullptr;  // 1
+    double *tick_pose = nullptr;     // 7 (base pose of the current tick, device)
+};
+
+int reloc_scratch(reloc_ctx *ctx, int slot, int64_t bytes, void **out);
+void reloc_prof_begin(reloc_ctx *ctx, int which);
+void reloc_prof_end(reloc_ctx *ctx, int which);
+
+// launchers shared between translation units
+// rec_ids == NULL: scan records 0..n_ids_max-1 and write counts[record]; otherwise scan the listed
+// records (count read from n_ids_dev when non-NULL) and write slot-indexed outputs.
+int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
+                   const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
+                   const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
+                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride);
+int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures);
+int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,
+                int nfeatures);
+int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4],
+                       int iters, float thr_px, double conf, uint64_t seed);

@@ -1,0 +1,605 @@
+// reloc_match.hip -- 256-bit Hamming matching on gfx950 (CDNA4), XOR + popcount on the VALU.
+//
+// Serves cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match        (reference M:211,327; G:337)
+//        cv2.BFMatcher(NORM_HAMMING, crossCheck=False).knnMatch k=2 (reference S:46,68)
+//        the whole-database candidate scoring of variant G          (reference G:329-344)
+// and the all-pairs u16 distance matrix of BASELINE.json config 5.
+//
+// No MFMA: this is bitwise work.  Instruction costs measured on MI355X (tools/ubench_valu.hip,
+// profiles/ubench_valu_r1.log): v_xor/v_or/v_and/v_add_u32 and the 16-bit v_min_u16 /
+// v_lshlrev_b16 issue in ~2.5 cycles per wave64, while v_bcnt_u32_b32, 32-bit min/shift and every
+// three-operand VOP3 (v_lshl_or, v_min3, v_add3...) take ~4.2.  The kernels are built around that:
+//   - the accumulate form  v_bcnt_u32_b32 D, S0, S1 (D = popcount(S0) + S1)  keeps a 256-bit pair
+//     at 8 xor + 8 bcnt (about 54 cycles per 64 pairs per SIMD: the floor of this problem);
+//   - the argmin bookkeeping uses 16-bit keys (distance << 4 | index) with v_lshlrev_b16, v_or_b32
+//     and v_min_u16, all in the cheap class.
+// Hot kernel (k_db_scan): a wave keeps all 512 current-frame descriptors (8 per lane, 64 VGPRs);
+// a database record's teach rows are wave-uniform, arrive through the scalar cache
+// (s_load_dwordx16) and feed the VALU as SGPR operands, so one 32-byte scalar fetch pays for 512
+// pairs and no LDS traffic is in the inner loop.  A record's rows are dealt in 16-row chunks to
+// the 4 waves of a workgroup.  Per chunk a wave produces (a) per lane and column the best row
+// (running 16-bit minimum), merged into LDS with ds_min_u32, and (b) per row the best column:
+// an in-lane 8-way 16-bit minimum, then a register-tile butterfly across lanes
+// (v_permlane16_swap / ds_bpermute).  Mutual nearest neighbours are resolved in LDS; the kernel
+// emits the per-record count and optionally the (queryIdx, trainIdx, distance) list in queryIdx
+// order.  Keys are (distance << k | index): the minimum of packed keys is the smallest distance
+// with the LOWEST index on ties, which is the tie rule of the specification.
+#include "reloc_internal.h"
+
+typedef uint32_t u32;
+
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc)
+{
+    u32 r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ u32 min_u16(u32 a, u32 b)
+{
+    u32 r;
+    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 shl4_u16(u32 a)
+{
+    u32 r;
+    asm("v_lshlrev_b16 %0, 4, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
+__device__ __forceinline__ u32 ham8(const u32 q[8], const uint4 a, const uint4 b, u32 init)
+{
+    u32 acc = init;
+    acc = bcnt_acc(q[0] ^ a.x, acc);
+    acc = bcnt_acc(q[1] ^ a.y, acc);
+    acc = bcnt_acc(q[2] ^ a.z, acc);
+    acc = bcnt_acc(q[3] ^ a.w, acc);
+    acc = bcnt_acc(q[4] ^ b.x, acc);
+    acc = bcnt_acc(q[5] ^ b.y, acc);
+    acc = bcnt_acc(q[6] ^ b.z, acc);
+    acc = bcnt_acc(q[7] ^ b.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 umax(u32 a, u32 b) { return a > b ? a : b; }
+
+// One butterfly exchange: on entry a = vector i, b = vector i+K on every lane.  On exit the
+// return value on lane l is min over lanes {l, l^K} of (bit K of l ? vector i+K : vector i).
+template <int K>
+__device__ __forceinline__ u32 bfly(u32 a, u32 b, int lane)
+{
+    if constexpr (K == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        return umin(r[0], r[1]);
+    } else if constexpr (K == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        return umin(r[0], r[1]);
+    } else {
+        const bool hi = lane & K;
+        const u32 mine = hi ? b : a;
+        const u32 theirs = hi ? a : b;
+        return umin(mine, (u32)__shfl_xor((int)theirs, K));
+    }
+}
+
+// Reduce 16 vectors (one value per lane each) to one: afterwards lane l holds the minimum over
+// all 64 lanes of vector (l mod 16).
+__device__ __forceinline__ u32 rows_min16(u32 (&d)[16], int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = bfly<8>(d[i], d[i + 8], lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = bfly<4>(d[i], d[i + 4], lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d[i] = bfly<2>(d[i], d[i + 2], lane);
+    u32 x = bfly<1>(d[0], d[1], lane);
+    x = umin(x, (u32)__shfl_xor((int)x, 16));
+    x = umin(x, (u32)__shfl_xor((int)x, 32));
+    return x;
+}
+
+constexpr int SCAN_CHUNK = 16;             // rows per chunk (4-bit row index inside the 16-bit key)
+constexpr u32 KEY_INVALID_BIAS = 512u;     // added to the distance of padding columns (> 256)
+
+// One 16-row chunk of a record against the wave's 512 columns.
+//   q[j]    : descriptor of column j*64 + lane (+ colbase); bias[j] = 0 or KEY_INVALID_BIAS
+//   CLAMP   : tail chunk, row indices clamped to the record's last row (a duplicate row offers
+//             the same distance with a larger index, so it never wins a minimum)
+template <bool CLAMP>
+__device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[8][8],
+                                           const u32 (&bias)[8], u32 colbase, u32 *rowkey, u32 *colbest,
+                                           bool single_cb, int lane)
+{
+    u32 cb16[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cb16[j] = 0xFFFFu;
+    u32 rk[SCAN_CHUNK];
+#pragma unroll
+    for (int t = 0; t < SCAN_CHUNK; t += 2) {
+        int r[2];
+        uint4 a[2], b[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            r[e] = CLAMP ? min(tc + t + e, n - 1) : tc + t + e;   // wave-uniform -> scalar loads
+            a[e] = rec[2 * r[e]];
+            b[e] = rec[2 * r[e] + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            u32 best = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32 kd = shl4_u16(ham8(q[j], a[e], b[e], bias[j]));   // (d << 4), 16 bit
+                cb16[j] = min_u16(cb16[j], kd | (u32)(t + e));             // best row of column j
+                const u32 rkj = kd | (u32)j;                               // best column of this row
+                best = j == 0 ? rkj : min_u16(best, rkj);
+            }
+            // 32-bit cross-lane key: distance << 16 | column
+            rk[t + e] = ((best >> 4) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
+        }
+    }
+    const u32 m = rows_min16(rk, lane);
+    const int row = tc + (lane & (SCAN_CHUNK - 1));
+    if (lane < SCAN_CHUNK && row < n) {
+        if (single_cb) rowkey[row] = m;
+        else atomicMin(&rowkey[row], m);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32 key = ((cb16[j] >> 4) << 16) | (u32)(tc + (int)(cb16[j] & 15u));
+        atomicMin(&colbest[colbase + j * 64 + lane], key);
+    }
+}
+
+// grid: any; block: 256 (4 waves).  Dynamic LDS: (ncb*512 + max_rows + 16) * 4 bytes.
+template <bool EMIT>
+__global__ __launch_bounds__(256, 4) void k_db_scan(
+    const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
+    const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
+    const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
+    int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
+    int32_t *__restrict__ m_n, int emit_stride)
+{
+    extern __shared__ u32 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row fetches stay scalar
+    const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
+    const int n_ids = n_ids_p ? min(*n_ids_p, n_ids_max) : n_ids_max;
+    const int ncb = max((C + 511) >> 9, 1);
+    u32 *colbest = lds;                   // ncb * 512 : best (distance << 16 | row) per column
+    u32 *rowkey = colbest + ncb * 512;    // max_rows  : best (distance << 16 | column) per row
+    u32 *wsum = rowkey + max_rows;        // 16
+
+    u32 q[8][8], bias[8];
+    auto load_q = [&](int colbase) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = colbase + j * 64 + lane;
+            if (col < C) {
+                const uint4 a = cur[2 * col], b = cur[2 * col + 1];
+                q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+                q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
+                bias[j] = 0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q[j][k] = 0;
+                bias[j] = KEY_INVALID_BIAS;
+            }
+        }
+    };
+    if (ncb == 1) load_q(0);
+
+    for (int it = blockIdx.x; it < n_ids; it += gridDim.x) {
+        const int r = rec_ids ? rec_ids[it] : it;
+        const int64_t row0 = off[r];
+        const int n = (int)(off[r + 1] - row0);
+        const uint4 *rec = db + 2 * row0;
+        for (int i = tid; i < ncb * 512; i += 256) colbest[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += 256) rowkey[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        if (n > 0 && C > 0) {
+            for (int cb = 0; cb < ncb; ++cb) {
+                if (ncb > 1) load_q(cb * 512);
+                for (int tc = wave * SCAN_CHUNK; tc < n; tc += 4 * SCAN_CHUNK) {
+                    if (tc + SCAN_CHUNK <= n)
+                        scan_chunk<false>(rec, n, tc, q, bias, (u32)(cb * 512), rowkey, colbest, ncb == 1, lane);
+                    else
+                        scan_chunk<true>(rec, n, tc, q, bias, (u32)(cb * 512), rowkey, colbest, ncb == 1, lane);
+                }
+            }
+        }
+        __syncthreads();
+        // mutual resolution, in teach-row (queryIdx) order
+        u32 base = 0;
+        for (int rb = 0; rb < n; rb += 256) {
+            const int row = rb + tid;
+            bool mutual = false;
+            u32 key = 0;
+            if (row < n && C > 0) {
+                key = rowkey[row];
+                const u32 col = key & 0xFFFFu;
+                mutual = (colbest[col] & 0xFFFFu) == (u32)row;
+            }
+            const unsigned long long bal = __ballot(mutual);
+            if (lane == 0) wsum[wave] = (u32)__popcll(bal);
+            __syncthreads();
+            u32 before = base;
+            for (int w = 0; w < wave; ++w) before += wsum[w];
+            u32 total = 0;
+            for (int w = 0; w < 4; ++w) total += wsum[w];
+            if (EMIT && mutual) {
+                const u32 pos = before + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+                const int64_t o = (int64_t)it * emit_stride + pos;
+                m_qidx[o] = row;
+                m_tidx[o] = (int32_t)(key & 0xFFFFu);
+                m_dist[o] = (int32_t)(key >> 16);
+            }
+            base += total;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (counts) counts[EMIT ? it : r] = (int32_t)base;
+            if (EMIT && m_n) m_n[it] = (int32_t)base;
+        }
+    }
+}
+
+int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
+                   const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
+                   const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
+                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride)
+{
+    if (n_ids_max <= 0) return RELOC_OK;
+    if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
+    if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
+    const int ncb = (n_cur_max + 511) / 512 > 0 ? (n_cur_max + 511) / 512 : 1;
+    if (max_rows < 1) max_rows = 1;
+    const size_t lds = (size_t)(ncb * 512 + max_rows + 16) * 4;
+    if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
+    int grid = ctx->num_cu * 4;
+    if (grid > n_ids_max) grid = n_ids_max;
+    const bool emit = m_qidx != nullptr;
+    if (emit)
+        hipLaunchKernelGGL(k_db_scan<true>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+    else
+        hipLaunchKernelGGL(k_db_scan<false>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic two-nearest-neighbour search: lane = one row of A, B rows stream through the scalar
+// cache.  key = distance << 22 | index (nb < 2^22).  grid.x tiles A rows, grid.y splits B.
+// Partial results (2 keys per A row per split) are merged by k_knn2_merge.
+__global__ __launch_bounds__(256) void k_knn2(const uint4 *__restrict__ A, int na, const uint4 *__restrict__ B,
+                                              int nb, int rows_per_split, u32 *__restrict__ part)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * rows_per_split;
+    const int j1 = min(nb, j0 + rows_per_split);
+    u32 q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < na) {
+        const uint4 a = A[2 * i], b = A[2 * i + 1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    u32 k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const u32 h = ham8(q, B[2 * j], B[2 * j + 1], 0);
+        const u32 key = (h << 22) | (u32)j;
+        const u32 m = umax(k0, key);
+        k0 = umin(k0, key);
+        k1 = umin(k1, m);
+    }
+    if (i < na) {
+        part[((size_t)blockIdx.y * na + i) * 2] = k0;
+        part[((size_t)blockIdx.y * na + i) * 2 + 1] = k1;
+    }
+}
+
+__global__ void k_knn2_merge(const u32 *__restrict__ part, int na, int nsplit, int32_t *__restrict__ idx,
+                             int32_t *__restrict__ dist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    u32 k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+    for (int s = 0; s < nsplit; ++s)
+        for (int e = 0; e < 2; ++e) {
+            const u32 key = part[((size_t)s * na + i) * 2 + e];
+            const u32 m = umax(k0, key);
+            k0 = umin(k0, key);
+            k1 = umin(k1, m);
+        }
+    idx[2 * i] = k0 == 0xFFFFFFFFu ? -1 : (int32_t)(k0 & 0x3FFFFFu);
+    dist[2 * i] = k0 == 0xFFFFFFFFu ? -1 : (int32_t)(k0 >> 22);
+    idx[2 * i + 1] = k1 == 0xFFFFFFFFu ? -1 : (int32_t)(k1 & 0x3FFFFFu);
+    dist[2 * i + 1] = k1 == 0xFFFFFFFFu ? -1 : (int32_t)(k1 >> 22);
+}
+
+// ---------------------------------------------------------------------------------------------
+// All-pairs u16 distance matrix.  Each lane keeps 8 consecutive B rows (64 VGPRs); A rows stream
+// through the scalar cache; per A row a lane produces 8 distances packed into one 16-byte store,
+// so a wave writes 1 KiB of one output row per instruction (HBM-write-bound shape).
+// grid.x = column tiles of 2048 (4 waves x 64 lanes x 8), grid.y = row tiles of MAT_ROWS.
+constexpr int MAT_ROWS = 128;
+
+struct MatRows { uint4 a[4], b[4]; };   // four A rows (wave-uniform: lives in SGPRs)
+
+__device__ __forceinline__ MatRows mat_load(const uint4 *__restrict__ A, int64_t i, int64_t last)
+{
+    MatRows r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t ii = i + e < last ? i + e : last;
+        r.a[e] = A[2 * ii];
+        r.b[e] = A[2 * ii + 1];
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint4 *__restrict__ A, int64_t na,
+                                                        const uint4 *__restrict__ B, int64_t nb,
+                                                        uint16_t *__restrict__ out)
+{
+    const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const int64_t i0 = (int64_t)blockIdx.y * MAT_ROWS;
+    const int64_t i1 = i0 + MAT_ROWS < na ? i0 + MAT_ROWS : na;
+    u32 b[8][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int64_t j = j0 + c < nb ? j0 + c : nb - 1;
+        const uint4 lo = B[2 * j], hi = B[2 * j + 1];
+        b[c][0] = lo.x; b[c][1] = lo.y; b[c][2] = lo.z; b[c][3] = lo.w;
+        b[c][4] = hi.x; b[c][5] = hi.y; b[c][6] = hi.z; b[c][7] = hi.w;
+    }
+    if (j0 >= nb) return;
+    const bool full = j0 + 8 <= nb;
+    // software pipeline: the scalar fetch of rows i+4..i+7 is in flight while rows i..i+3 are
+    // computed, and the four 16-byte stores of a group stay outstanding into the next group.
+    MatRows nxt = mat_load(A, i0, na - 1);
+    for (int64_t i = i0; i < i1; i += 4) {
+        const MatRows cur = nxt;
+        nxt = mat_load(A, i + 4 < na ? i + 4 : na - 1, na - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32 w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const u32 odd = ham8(b[2 * p + 1], cur.a[e], cur.b[e], 0);
+                w[p] = ham8(b[2 * p], cur.a[e], cur.b[e], odd << 16);
+            }
+            if (i + e < i1) {
+                uint16_t *o = out + (i + e) * nb + j0;
+                if (full) {
+                    *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else {
+                    for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
+                }
+            }
+        }
+    }
+}
+
+// slow path for outputs whose rows are not 16-byte aligned (nb % 8 != 0)
+__global__ void k_hamming_matrix_any(const uint4 *__restrict__ A, int64_t na, const uint4 *__restrict__ B,
+                                     int64_t nb, uint16_t *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * MAT_ROWS;
+    const int64_t i1 = i0 + MAT_ROWS < na ? i0 + MAT_ROWS : na;
+    if (j >= nb) return;
+    u32 q[8];
+    const uint4 lo = B[2 * j], hi = B[2 * j + 1];
+    q[0] = lo.x; q[1] = lo.y; q[2] = lo.z; q[3] = lo.w; q[4] = hi.x; q[5] = hi.y; q[6] = hi.z; q[7] = hi.w;
+    for (int64_t i = i0; i < i1; ++i) out[i * nb + j] = (uint16_t)ham8(q, A[2 * i], A[2 * i + 1], 0);
+}
+
+static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb, uint16_t *out)
+{
+    if (na <= 0 || nb <= 0) return RELOC_OK;
+    const int64_t gy = (na + MAT_ROWS - 1) / MAT_ROWS;
+    if (gy > 65535 * 16) { reloc_set_error("hamming matrix: too many rows"); return RELOC_E_CAPACITY; }
+    reloc_prof_begin(ctx, RELOC_PROF_MATRIX);
+    if (nb % 8 == 0 && ((uintptr_t)out & 15) == 0) {
+        dim3 grid((unsigned)((nb + 2047) / 2048), (unsigned)gy);
+        hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, ctx->stream, (const uint4 *)a, na, (const uint4 *)b, nb, out);
+    } else {
+        dim3 grid((unsigned)((nb + 255) / 256), (unsigned)gy);
+        hipLaunchKernelGGL(k_hamming_matrix_any, grid, dim3(256), 0, ctx->stream, (const uint4 *)a, na, (const uint4 *)b, nb, out);
+    }
+    reloc_prof_end(ctx, RELOC_PROF_MATRIX);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI entry points
+RELOC_API int reloc_hamming_matrix_dev(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,
+                                       uint16_t *out)
+{
+    ARG_CHECK(ctx && a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix_dev");
+    ARG_CHECK((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "descriptor arrays must be 16-byte aligned");
+    return launch_matrix(ctx, a, na, b, nb, out);
+}
+
+RELOC_API int reloc_hamming_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,
+                                   uint16_t *out)
+{
+    ARG_CHECK(ctx && a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix");
+    if (na == 0 || nb == 0) return RELOC_OK;
+    void *da, *db, *dout;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, na * 32, &da))) return rc;
+    if ((rc = reloc_scratch(ctx, 1, nb * 32, &db))) return rc;
+    if ((rc = reloc_scratch(ctx, 2, na * nb * 2, &dout))) return rc;
+    HIP_TRY(hipMemcpyAsync(da, a, (size_t)na * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db, b, (size_t)nb * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_matrix(ctx, (const uint8_t *)da, na, (const uint8_t *)db, nb, (uint16_t *)dout))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)na * nb * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_match_knn2(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx,
+                               int32_t *dist)
+{
+    ARG_CHECK(ctx && nq >= 0 && nt >= 0 && (nq == 0 || (q && idx && dist)) && (nt == 0 || t), "reloc_match_knn2");
+    if (nq == 0) return RELOC_OK;
+    if (nt == 0) {
+        for (int i = 0; i < 2 * nq; ++i) { idx[i] = -1; dist[i] = -1; }
+        return RELOC_OK;
+    }
+    if (nt >= (1 << 22)) { reloc_set_error("knn2: train set too large"); return RELOC_E_CAPACITY; }
+    int nsplit = (int)((int64_t)ctx->num_cu * 4 / ((nq + 255) / 256));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > (nt + 63) / 64) nsplit = (nt + 63) / 64;
+    const int rows_per_split = (nt + nsplit - 1) / nsplit;
+    nsplit = (nt + rows_per_split - 1) / rows_per_split;
+    void *dq, *dt, *dpart, *dout;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)nq * 32, &dq))) return rc;
+    if ((rc = reloc_scratch(ctx, 1, (int64_t)nt * 32, &dt))) return rc;
+    if ((rc = reloc_scratch(ctx, 2, (int64_t)nsplit * nq * 8, &dpart))) return rc;
+    if ((rc = reloc_scratch(ctx, 3, (int64_t)nq * 16, &dout))) return rc;
+    HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 255) / 256, nsplit), dim3(256), 0, ctx->stream, (const uint4 *)dq, nq,
+                       (const uint4 *)dt, nt, rows_per_split, (u32 *)dpart);
+    int32_t *didx = (int32_t *)dout, *ddist = didx + 2 * (size_t)nq;
+    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)dpart, nq, nsplit,
+                       didx, ddist);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dist, ddist, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *qidx,
+                                 int32_t *tidx, int32_t *dist, int32_t *n_out)
+{
+    ARG_CHECK(ctx && n_out && nq >= 0 && nt >= 0, "reloc_match_mutual");
+    *n_out = 0;
+    if (nq == 0 || nt == 0) return RELOC_OK;
+    ARG_CHECK(q && t && qidx && tidx && dist, "reloc_match_mutual: NULL array");
+    if (nq > MAX_REC_ROWS) { reloc_set_error("match: query set larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
+    void *dq, *dt, *dm;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)nq * 32 + 64, &dq))) return rc;
+    if ((rc = reloc_scratch(ctx, 1, (int64_t)nt * 32, &dt))) return rc;
+    if ((rc = reloc_scratch(ctx, 2, (int64_t)nq * 12 + 64, &dm))) return rc;
+    // offsets {0, nq} live in front of the match arrays
+    int64_t offs[2] = {0, nq};
+    int64_t *doff = (int64_t *)dm;
+    int32_t *dn = (int32_t *)(doff + 2);
+    int32_t *dqi = dn + 4, *dti = dqi + nq, *ddi = dti + nq;
+    HIP_TRY(hipMemcpyAsync(doff, offs, sizeof(offs), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_db_scan(ctx, (const uint8_t *)dq, doff, 1, nullptr, nullptr, 1, (const uint8_t *)dt, nullptr, nt,
+                             nq, nullptr, dqi, dti, ddi, dn, nq)))
+        return rc;
+    int32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(qidx, dqi, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(tidx, dti, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dist, ddi, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n;
+    return RELOC_OK;
+}
+
+// ---- database ---------------------------------------------------------------------------------
+__global__ void k_db_index(const double *__restrict__ pose, int64_t n, double *__restrict__ xyh)
+{
+    // heading of base_link +X in the world from the stored CAMERA pose (reference M:233-245):
+    // R_wb = R_wc * R_bc^T with R_bc = [[0,-1,0],[0,0,-1],[1,0,0]]; fwd = R_wb[:,0] = R_wc[:,2]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double qx = pose[7 * i + 3], qy = pose[7 * i + 4], qz = pose[7 * i + 5], qw = pose[7 * i + 6];
+    const double fx = 2 * (qx * qz + qy * qw), fy = 2 * (qy * qz - qx * qw);
+    xyh[3 * i] = pose[7 * i];
+    xyh[3 * i + 1] = pose[7 * i + 1];
+    xyh[3 * i + 2] = atan2(fy, fx);
+}
+
+RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const int64_t *offsets,
+                              const double *poses, int64_t n_records)
+{
+    ARG_CHECK(ctx && offsets && n_records >= 0, "reloc_db_upload");
+    const int64_t T = offsets[n_records];
+    ARG_CHECK(offsets[0] == 0 && T >= 0, "offsets must start at 0 and be non-decreasing");
+    int maxrows = 0;
+    for (int64_t r = 0; r < n_records; ++r) {
+        const int64_t n = offsets[r + 1] - offsets[r];
+        ARG_CHECK(n >= 0, "offsets must be non-decreasing");
+        if (n > MAX_REC_ROWS) { reloc_set_error("record %lld has %lld rows (max %d)", (long long)r, (long long)n, MAX_REC_ROWS); return RELOC_E_CAPACITY; }
+        if (n > maxrows) maxrows = (int)n;
+    }
+    ARG_CHECK(T == 0 || (desc && pts3d), "desc / pts3d missing");
+    ARG_CHECK(n_records == 0 || poses, "poses missing");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    void **olds[] = {(void **)&ctx->db_desc, (void **)&ctx->db_pts3d, (void **)&ctx->db_off, (void **)&ctx->db_pose,
+                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts};
+    for (void **p : olds) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
+    HIP_TRY(hipMalloc((void **)&ctx->db_desc, (size_t)(T > 0 ? T : 1) * 32));
+    HIP_TRY(hipMalloc((void **)&ctx->db_pts3d, (size_t)(T > 0 ? T : 1) * 12));
+    HIP_TRY(hipMalloc((void **)&ctx->db_off, (size_t)(n_records + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&ctx->db_pose, (size_t)(n_records > 0 ? n_records : 1) * 56));
+    HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 24));
+    HIP_TRY(hipMalloc((void **)&ctx->db_counts, (size_t)(n_records > 0 ? n_records : 1) * 4));
+    if (T > 0) {
+        HIP_TRY(hipMemcpyAsync(ctx->db_desc, desc, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->db_pts3d, pts3d, (size_t)T * 12, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->db_off, offsets, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_records > 0) {
+        HIP_TRY(hipMemcpyAsync(ctx->db_pose, poses, (size_t)n_records * 56, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_db_index, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, ctx->db_pose,
+                           n_records, ctx->db_xy_heading);
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->db_records = n_records;
+    ctx->db_rows = T;
+    ctx->db_max_rows = maxrows;
+    return RELOC_OK;
+}
+
+RELOC_API int64_t reloc_db_records(reloc_ctx *ctx) { return ctx ? ctx->db_records : -1; }
+RELOC_API int64_t reloc_db_rows(reloc_ctx *ctx) { return ctx ? ctx->db_rows : -1; }
+
+RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, const int32_t *n_cur_dev, int n_cur_max,
+                                        int32_t *counts_dev)
+{
+    ARG_CHECK(ctx && cur_dev && counts_dev && n_cur_max >= 0, "reloc_db_match_counts_dev");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
+    int rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, cur_dev,
+                            n_cur_dev, n_cur_max, ctx->db_max_rows, counts_dev, nullptr, nullptr, nullptr, nullptr, 0);
+    reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+    return rc;
+}
+
+RELOC_API int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts)
+{
+    ARG_CHECK(ctx && counts && n_cur >= 0 && (n_cur == 0 || cur), "reloc_db_match_counts");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
+    void *dc;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)n_cur * 32, &dc))) return rc;
+    HIP_TRY(hipMemcpyAsync(dc, cur, (size_t)n_cur * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = reloc_db_match_counts_dev(ctx, (const uint8_t *)dc, nullptr, n_cur, ctx->db_counts))) return rc;
+    HIP_TRY(hipMemcpyAsync(counts, ctx->db_counts, (size_t)ctx->db_records * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
+}

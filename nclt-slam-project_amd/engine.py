@@ -1,0 +1,237 @@
+"""Engine: one reloc_ctx (one HIP stream, one optional landmark database) with numpy in / numpy out
+methods.  This is the object the cv2-shaped shim, the matcher/recorder nodes and bench.py share.
+
+Every method calls the HIP library through the C-ABI of include/reloc.h; nothing falls back to
+a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+K4_DEFAULT = np.array([320.0, 320.0, 320.0, 240.0], dtype=np.float64)  # fx fy cx cy (reference M:49-52)
+
+OUTCOME_NAMES = {0: "published", 1: "curr_no_features", 2: "no_candidates", 3: "no_pnp_accept",
+                 4: "consistency_fail"}
+
+
+class Engine:
+    def __init__(self, device: int = 0, max_w: int = 1280, max_h: int = 720, max_feat: int = 8192):
+        self._lib = N.load()
+        self._ctx = self._lib.reloc_create(device, max_w, max_h, max_feat)
+        if not self._ctx:
+            raise N.RelocError("reloc_create failed: " + N.last_error())
+        self.device = device
+        self.max_w, self.max_h, self.max_feat = max_w, max_h, max_feat
+
+    # ------------------------------------------------------------------ lifetime / plumbing
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.reloc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def set_stream(self, hip_stream: int | None):
+        N.check(self._lib.reloc_set_stream(self._ctx, C.c_void_p(hip_stream or 0)), "reloc_set_stream")
+
+    def sync(self):
+        N.check(self._lib.reloc_sync(self._ctx), "reloc_sync")
+
+    def dev_alloc(self, nbytes: int) -> int:
+        p = self._lib.reloc_dev_alloc(self._ctx, int(nbytes))
+        if not p:
+            raise N.RelocError("reloc_dev_alloc failed: " + N.last_error())
+        return int(p)
+
+    def dev_free(self, p: int):
+        N.check(self._lib.reloc_dev_free(self._ctx, C.c_void_p(p)), "reloc_dev_free")
+
+    def h2d(self, dst_dev: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        N.check(self._lib.reloc_h2d(self._ctx, C.c_void_p(dst_dev), N.ptr(src), src.nbytes), "reloc_h2d")
+        self.sync()
+
+    def d2h(self, dst: np.ndarray, src_dev: int):
+        assert dst.flags["C_CONTIGUOUS"]
+        N.check(self._lib.reloc_d2h(self._ctx, N.ptr(dst), C.c_void_p(src_dev), dst.nbytes), "reloc_d2h")
+        self.sync()
+
+    def to_device(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a)
+        p = self.dev_alloc(max(a.nbytes, 16))
+        self.h2d(p, a)
+        return p
+
+    def timer_begin(self):
+        N.check(self._lib.reloc_timer_begin(self._ctx), "reloc_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        N.check(self._lib.reloc_timer_end(self._ctx, C.byref(ms)), "reloc_timer_end")
+        return ms.value
+
+    def profile_enable(self, on: bool):
+        N.check(self._lib.reloc_profile_enable(self._ctx, int(on)), "reloc_profile_enable")
+
+    def profile_get(self, which: int):
+        ms = C.c_float(); n = C.c_int32()
+        N.check(self._lib.reloc_profile_get(self._ctx, which, C.byref(ms), C.byref(n)), "reloc_profile_get")
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ ORB front end
+    def gray(self, img: np.ndarray, order_rgb: bool = False) -> np.ndarray:
+        img = N.u8(img)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise N.RelocError("gray: expected an (H, W, 3) uint8 image")
+        h, w, _ = img.shape
+        out = np.empty((h, w), np.uint8)
+        N.check(self._lib.reloc_gray_u8(self._ctx, N.ptr(img), w, h, w * 3, int(order_rgb), N.ptr(out)), "reloc_gray_u8")
+        return out
+
+    def orb_detect_compute(self, gray: np.ndarray, nfeatures: int = 500):
+        gray = N.u8(gray)
+        if gray.ndim != 2:
+            raise N.RelocError("detectAndCompute: expected an (H, W) uint8 image")
+        h, w = gray.shape
+        mf = self.max_feat
+        xy = np.empty((mf, 2), np.float32); size = np.empty(mf, np.float32); ang = np.empty(mf, np.float32)
+        resp = np.empty(mf, np.float32); octv = np.empty(mf, np.int32); desc = np.empty((mf, 32), np.uint8)
+        n = C.c_int32()
+        N.check(self._lib.reloc_orb_detect_compute(self._ctx, N.ptr(gray), w, h, w, int(nfeatures), N.ptr(xy), N.ptr(size),
+                                                   N.ptr(ang), N.ptr(resp), N.ptr(octv), N.ptr(desc), C.byref(n)),
+                "reloc_orb_detect_compute")
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=ang[:k].copy(), response=resp[:k].copy(),
+                    octave=octv[:k].copy(), desc=desc[:k].copy(), n=k)
+
+    def frame_debug_plane(self, what: int, level: int) -> np.ndarray:
+        buf = np.empty(self.max_w * self.max_h, np.uint8)
+        w = C.c_int32(); h = C.c_int32()
+        N.check(self._lib.reloc_frame_debug_plane(self._ctx, what, level, N.ptr(buf), C.byref(w), C.byref(h)),
+                "reloc_frame_debug_plane")
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
+
+    # ------------------------------------------------------------------ matching
+    @staticmethod
+    def _desc(a, name):
+        a = np.asarray(a)
+        if a.dtype != np.uint8 or a.ndim != 2 or a.shape[1] != 32:
+            raise N.RelocError(f"{name}: descriptors must be (N, 32) uint8, got {a.dtype} {a.shape}")
+        return np.ascontiguousarray(a)
+
+    def match_mutual(self, q, t):
+        q = self._desc(q, "match"); t = self._desc(t, "match")
+        cap = max(min(len(q), len(t)), 1)
+        qi = np.empty(cap, np.int32); ti = np.empty(cap, np.int32); dd = np.empty(cap, np.int32)
+        n = C.c_int32()
+        N.check(self._lib.reloc_match_mutual(self._ctx, N.ptr(q), len(q), N.ptr(t), len(t), N.ptr(qi), N.ptr(ti),
+                                             N.ptr(dd), C.byref(n)), "reloc_match_mutual")
+        return qi[: n.value].copy(), ti[: n.value].copy(), dd[: n.value].copy()
+
+    def match_knn2(self, q, t):
+        q = self._desc(q, "knnMatch"); t = self._desc(t, "knnMatch")
+        idx = np.empty((len(q), 2), np.int32); dist = np.empty((len(q), 2), np.int32)
+        N.check(self._lib.reloc_match_knn2(self._ctx, N.ptr(q), len(q), N.ptr(t), len(t), N.ptr(idx), N.ptr(dist)),
+                "reloc_match_knn2")
+        return idx, dist
+
+    def db_upload(self, desc, pts3d, offsets, poses):
+        desc = self._desc(desc, "db_upload") if len(desc) else np.zeros((0, 32), np.uint8)
+        pts3d = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        if len(offsets) != len(poses) + 1 or offsets[-1] != len(desc) or len(pts3d) != len(desc):
+            raise N.RelocError("db_upload: inconsistent array sizes")
+        N.check(self._lib.reloc_db_upload(self._ctx, N.ptr(desc), N.ptr(pts3d), N.ptr(offsets), N.ptr(poses),
+                                          len(poses)), "reloc_db_upload")
+
+    @property
+    def db_records(self) -> int:
+        return int(self._lib.reloc_db_records(self._ctx))
+
+    @property
+    def db_rows(self) -> int:
+        return int(self._lib.reloc_db_rows(self._ctx))
+
+    def db_match_counts(self, cur):
+        cur = self._desc(cur, "db_match_counts") if len(cur) else np.zeros((0, 32), np.uint8)
+        counts = np.empty(self.db_records, np.int32)
+        N.check(self._lib.reloc_db_match_counts(self._ctx, N.ptr(cur), len(cur), N.ptr(counts)), "reloc_db_match_counts")
+        return counts
+
+    def db_match_counts_dev(self, cur_dev: int, n_cur: int, counts_dev: int, n_cur_dev: int = 0):
+        N.check(self._lib.reloc_db_match_counts_dev(self._ctx, C.c_void_p(cur_dev), C.c_void_p(n_cur_dev), int(n_cur),
+                                                    C.c_void_p(counts_dev)), "reloc_db_match_counts_dev")
+
+    def hamming_matrix(self, a, b):
+        a = self._desc(a, "hamming_matrix"); b = self._desc(b, "hamming_matrix")
+        out = np.empty((len(a), len(b)), np.uint16)
+        N.check(self._lib.reloc_hamming_matrix(self._ctx, N.ptr(a), len(a), N.ptr(b), len(b), N.ptr(out)),
+                "reloc_hamming_matrix")
+        return out
+
+    def hamming_matrix_dev(self, a_dev: int, na: int, b_dev: int, nb: int, out_dev: int):
+        N.check(self._lib.reloc_hamming_matrix_dev(self._ctx, C.c_void_p(a_dev), na, C.c_void_p(b_dev), nb,
+                                                   C.c_void_p(out_dev)), "reloc_hamming_matrix_dev")
+
+    # ------------------------------------------------------------------ PnP
+    def pnp_score(self, obj, img, Rt, K4=K4_DEFAULT, thr_px=3.0, want_mask=False):
+        obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+        img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+        Rt = np.ascontiguousarray(Rt, np.float64).reshape(-1, 12)
+        K4 = np.ascontiguousarray(K4, np.float64)
+        cnt = np.empty(len(Rt), np.int32)
+        mask = np.empty((len(Rt), len(obj)), np.uint8) if want_mask else None
+        N.check(self._lib.reloc_pnp_score(self._ctx, N.ptr(obj), N.ptr(img), len(obj), N.ptr(Rt), len(Rt), N.ptr(K4),
+                                          float(thr_px), N.ptr(cnt), N.ptr(mask)), "reloc_pnp_score")
+        return (cnt, mask) if want_mask else cnt
+
+    def pnp_ransac(self, obj, img, K4=K4_DEFAULT, iters=200, thr_px=3.0, conf=0.99, seed=0):
+        obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+        img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+        if len(obj) != len(img):
+            raise N.RelocError("solvePnPRansac: object/image point counts differ")
+        K4 = np.ascontiguousarray(K4, np.float64)
+        rvec = np.zeros(3); tvec = np.zeros(3)
+        inl = np.empty(max(len(obj), 1), np.int32)
+        n = C.c_int32(); ok = C.c_int32()
+        N.check(self._lib.reloc_pnp_ransac(self._ctx, N.ptr(obj), N.ptr(img), len(obj), N.ptr(K4), int(iters),
+                                           float(thr_px), float(conf), int(seed), N.ptr(rvec), N.ptr(tvec), N.ptr(inl),
+                                           C.byref(n), C.byref(ok)), "reloc_pnp_ransac")
+        return bool(ok.value), rvec, tvec, inl[: n.value].copy()
+
+    # ------------------------------------------------------------------ fused tick
+    def tick(self, img, base_pose, order_rgb=False, global_reloc=False, seed=0):
+        img = N.u8(img)
+        h, w, _ = img.shape
+        bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
+        anchor = np.zeros(7); n_inl = C.c_int32(); rep = C.c_float(); lm = C.c_int32(); oc = C.c_int32(); nc = C.c_int32()
+        N.check(self._lib.reloc_tick(self._ctx, N.ptr(img), w, h, int(order_rgb), N.ptr(bp), int(global_reloc), int(seed),
+                                     N.ptr(anchor), C.byref(n_inl), C.byref(rep), C.byref(lm), C.byref(oc), C.byref(nc)),
+                "reloc_tick")
+        return dict(anchor_pose=anchor, n_inliers=n_inl.value, reproj=rep.value, lm_idx=lm.value, outcome=oc.value,
+                    n_candidates=nc.value)
+
+    def tick_dev(self, img_dev: int, w: int, h: int, base_pose, order_rgb=False, global_reloc=False, seed=0):
+        bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
+        N.check(self._lib.reloc_tick_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
+                                         int(global_reloc), int(seed)), "reloc_tick_dev")
+
+    def tick_result(self):
+        anchor = np.zeros(7); n_inl = C.c_int32(); rep = C.c_float(); lm = C.c_int32(); oc = C.c_int32(); nc = C.c_int32()
+        N.check(self._lib.reloc_tick_result(self._ctx, N.ptr(anchor), C.byref(n_inl), C.byref(rep), C.byref(lm),
+                                            C.byref(oc), C.byref(nc)), "reloc_tick_result")
+        return dict(anchor_pose=anchor, n_inliers=n_inl.value, reproj=rep.value, lm_idx=lm.value, outcome=oc.value,
+                    n_candidates=nc.value)
