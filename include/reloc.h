@@ -140,6 +140,12 @@ int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *img, int m, 
                      int iters, float thr_px, double conf, uint64_t seed, double rvec[3],
                      double tvec[3], int32_t *inliers, int32_t *n_inl, int32_t *ok);
 
+/* Camera model used by the fused tick: K4 = fx fy cx cy (M:49-52) and the static base_link ->
+ * camera transform stored in landmarks.pkl (M:183-184; R:81-88).  NULL keeps the current value;
+ * the defaults are the reference's constants. */
+int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double base_to_cam_t[3],
+                     const double base_to_cam_R[9]);
+
 /* ---- fused tick ----------------------------------------------------------------------------- */
 /* One repeat tick against the uploaded database (M:281-433 with G:315-344's whole-database
  * candidate search when global_reloc != 0): gray -> ORB -> candidates -> mutual match ->
@@ -156,6 +162,9 @@ int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int ord
                    const double base_pose[7], int global_reloc, uint64_t seed);
 int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
                       int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
+/* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12). */
+int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches,
+                     int32_t *n_inl, int32_t *ok, double *reproj, double *Rt);
 /* Sharded database (one rank per GPU): per-record mutual-match counts are local; the caller
  * exchanges the per-shard top-k (count, global id) lists and tells each rank which of ITS
  * records made the global top-k.  These two calls split reloc_tick_dev at that exchange. */

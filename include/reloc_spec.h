@@ -25,7 +25,7 @@
 /* Capacity of the per-level "best 2*quota by FAST score, ties kept" set.  If more pixels
  * than this reach the cut score the cut is raised one score at a time until the set fits
  * (decided from the score histogram alone, so the rule is order-independent). */
-#define RELOC_ORB_STAGE1_CAP     8192
+#define RELOC_ORB_STAGE1_CAP     4096
 
 /* BGR->gray 8-bit fixed point: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14 */
 #define RELOC_GRAY_CB            1868

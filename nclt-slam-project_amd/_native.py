@@ -51,6 +51,8 @@ SIGNATURES = {
     "reloc_hamming_matrix_dev": (C.c_int, [c_ctx, P, i64, P, i64, P]),
     "reloc_pnp_score": (C.c_int, [c_ctx, P, P, C.c_int, P, C.c_int, P, f32, P, P]),
     "reloc_pnp_ransac": (C.c_int, [c_ctx, P, P, C.c_int, P, C.c_int, f32, f64, u64, P, P, P, P, P]),
+    "reloc_set_camera": (C.c_int, [c_ctx, P, P, P]),
+    "reloc_tick_debug": (C.c_int, [c_ctx, P, P, P, P, P, P, P]),
     "reloc_tick": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64, P, P, P, P, P, P]),
     "reloc_tick_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64]),
     "reloc_tick_result": (C.c_int, [c_ctx, P, P, P, P, P, P]),

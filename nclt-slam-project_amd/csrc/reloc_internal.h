@@ -104,7 +104,14 @@ struct reloc_ctx {
     int32_t *f_count = nullptr;
     uint8_t *frame_gray = nullptr; // unused when level 0 is written directly
     uint8_t *frame_img = nullptr;  // staging for host frames (max_w*max_h*3)
-    void *orb_const = nullptr;     // device copy of level table
+    void *orb_const = nullptr;     // device copy of the OrbTable (reloc_orb.hip)
+    char orb_tab_host[1024];       // host copy of the same table
+    int32_t *dbg_cut = nullptr;    // NLEV stage-1 cut scores of the last frame
+
+    // ---- camera (reference M:49-52, M:107-112) ----
+    double K4[4] = {RELOC_FX, RELOC_FY, RELOC_CX, RELOC_CY};
+    double b2c_t[3] = {0.35, 0.0, 0.18};
+    double b2c_R[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
 
     // ---- database ----
     int64_t db_records = 0, db_rows = 0;
@@ -140,8 +147,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
                    int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride);
+int db_reindex(reloc_ctx *ctx);
 int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures);
 int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,
                 int nfeatures);
 int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4],
-                       int iters, float thr_px, double conf, uint64_t seed);
+                       int iters, float thr_px, double conf, uint64_t seed, int min_m);

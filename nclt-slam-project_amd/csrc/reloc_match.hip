@@ -519,17 +519,29 @@ RELOC_API int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const
 }
 
 // ---- database ---------------------------------------------------------------------------------
-__global__ void k_db_index(const double *__restrict__ pose, int64_t n, double *__restrict__ xyh)
+__global__ void k_db_index(const double *__restrict__ pose, int64_t n, double b0, double b1, double b2,
+                           double *__restrict__ xyh)
 {
-    // heading of base_link +X in the world from the stored CAMERA pose (reference M:233-245):
-    // R_wb = R_wc * R_bc^T with R_bc = [[0,-1,0],[0,0,-1],[1,0,0]]; fwd = R_wb[:,0] = R_wc[:,2]
+    // heading of base_link +X in the world from the stored CAMERA pose, exactly as the reference
+    // composes it (M:233-245): R_wb = R_wc @ B.T, fwd = R_wb @ [1,0,0] = R_wc @ B[0,:]
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double qx = pose[7 * i + 3], qy = pose[7 * i + 4], qz = pose[7 * i + 5], qw = pose[7 * i + 6];
-    const double fx = 2 * (qx * qz + qy * qw), fy = 2 * (qy * qz - qx * qw);
+    const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
+    const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
+    const double fx = r00 * b0 + r01 * b1 + r02 * b2, fy = r10 * b0 + r11 * b1 + r12 * b2;
     xyh[3 * i] = pose[7 * i];
     xyh[3 * i + 1] = pose[7 * i + 1];
     xyh[3 * i + 2] = atan2(fy, fx);
+}
+
+int db_reindex(reloc_ctx *ctx)
+{
+    if (!ctx->db_pose || ctx->db_records <= 0) return RELOC_OK;
+    hipLaunchKernelGGL(k_db_index, dim3((unsigned)((ctx->db_records + 255) / 256)), dim3(256), 0, ctx->stream, ctx->db_pose,
+                       ctx->db_records, ctx->b2c_R[0], ctx->b2c_R[1], ctx->b2c_R[2], ctx->db_xy_heading);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
 }
 
 RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const int64_t *offsets,
@@ -564,13 +576,13 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     HIP_TRY(hipMemcpyAsync(ctx->db_off, offsets, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (n_records > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_pose, poses, (size_t)n_records * 56, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_db_index, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, ctx->db_pose,
-                           n_records, ctx->db_xy_heading);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->db_records = n_records;
     ctx->db_rows = T;
     ctx->db_max_rows = maxrows;
+    int rc = db_reindex(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RELOC_OK;
 }
 

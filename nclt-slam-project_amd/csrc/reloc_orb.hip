@@ -1,0 +1,746 @@
+// reloc_orb.hip -- ORB front end on gfx950: gray -> 8-level pyramid -> FAST-9/16 + NMS ->
+// best-2n by FAST score -> Harris -> best-n -> intensity-centroid angle -> 7x7 blur -> steered
+// BRIEF-256.  Serves cv2.cvtColor(.., COLOR_BGR2GRAY) and
+// cv2.ORB_create(nfeatures).detectAndCompute(gray, None)        (reference M:305-306, R:240-241).
+//
+// Everything is integer or strictly-ordered IEEE float arithmetic (no fused multiply-add, own
+// sin/cos) so results are bit-identical to the specification; the algorithm constants live in
+// include/reloc_spec.h.  Data layout in HBM: every pyramid level is a plane with a 64-byte-aligned
+// row stride inside one arena (ctx->pyr); the blurred pyramid (ctx->blur) and the NMS score maps
+// (ctx->nms) use the same geometry, so a level is addressed by one offset in all three.
+//
+// Launches per frame (all on the ctx stream):
+//   k_gray_l0 (or a 2-D copy)            3 B/px in, 1 B/px out, 4 px per lane (dword stores)
+//   k_resize  x7                         level l from level l-1, fixed-point INTER_LINEAR_EXACT
+//   k_blur7                              all levels, 64x16 tiles staged in LDS (8.8 / 16.16 passes)
+//   k_fast_nms                           all levels, 32x32 tiles + halo in LDS: score, 3x3 NMS,
+//                                        per-level score histogram (LDS atomics, then global)
+//   k_harris                             histogram -> cut score; survivors >= cut get a Harris
+//                                        response and enter the per-level candidate list
+//   k_select                             one workgroup per level: keep "fewer than quota strictly
+//                                        greater", order raster by rank counting
+//   k_describe                           one wave per keypoint: moments by wave reduction, angle,
+//                                        256 steered tests -> 4 ballots = 32 descriptor bytes
+// The per-frame HBM traffic is about 4 MB at 640x480; the stage is launch/latency-bound, not
+// bandwidth-bound.
+#include <math.h>
+
+#include "../../include/reloc_orb_pattern.h"
+#include "reloc_internal.h"
+
+typedef uint32_t u32;
+
+struct OrbTable {
+    OrbLevel lev[NLEV];
+    int fast_tile_base[NLEV + 1];   // 32x32 tiles over (stride x h)
+    int blur_tile_base[NLEV + 1];   // 64x16 tiles over (w x h)
+    int flat_base[NLEV + 1];        // 4096-byte chunks over stride*h
+    int rz_off[NLEV][4];            // offsets into the resize table: xofs, xcoef, yofs, ycoef
+};
+
+__constant__ signed char c_pattern[RELOC_ORB_NTESTS * 4];
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ signed char c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__constant__ signed char c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+__device__ __forceinline__ int find_level(const int *base, int id)
+{
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < NLEV; ++k) l += id >= base[k];
+    return l;
+}
+
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        if (p >= n) p = 2 * n - 2 - p;
+    }
+    return p;
+}
+
+// ---- gray ---------------------------------------------------------------------------------------
+// 4 pixels per lane: 12 source bytes -> one dword of level 0.  Block 0 also clears the per-frame
+// counters (histograms, candidate counts).
+__global__ __launch_bounds__(256) void k_gray_l0(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
+                                                 uint8_t *__restrict__ dst, int dstride, int32_t *__restrict__ hist,
+                                                 int32_t *__restrict__ cand_cnt)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < NLEV * 256; i += 256) hist[i] = 0;
+        if (threadIdx.x < NLEV) cand_cnt[threadIdx.x] = 0;
+    }
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x4 >= w) return;
+    const uint8_t *s = src + (size_t)y * sstride + 3 * x4;
+    u32 out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (x4 + k < w) {
+            const int c0 = s[3 * k], c1 = s[3 * k + 1], c2 = s[3 * k + 2];
+            const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
+            const int g = (b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
+            out |= (u32)g << (8 * k);
+        }
+    }
+    *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;
+}
+
+__global__ __launch_bounds__(256) void k_clear_counters(int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
+{
+    for (int i = threadIdx.x; i < NLEV * 256; i += 256) hist[i] = 0;
+    if (threadIdx.x < NLEV) cand_cnt[threadIdx.x] = 0;
+}
+
+// plain gray output for reloc_gray_u8 (dense rows)
+__global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
+                                                    uint8_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t *s = src + (size_t)y * sstride + 3 * x;
+    const int c0 = s[0], c1 = s[1], c2 = s[2];
+    const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
+    dst[(size_t)y * w + x] = (uint8_t)((b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT);
+}
+
+// ---- pyramid ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
+                                                uint8_t *__restrict__ dst, int dw, int dh, int dstride,
+                                                const int32_t *__restrict__ xofs, const int32_t *__restrict__ xcoef,
+                                                const int32_t *__restrict__ yofs, const int32_t *__restrict__ ycoef)
+{
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x4 >= dstride) return;
+    const int y0 = yofs[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+    const u32 b = (u32)ycoef[y];
+    const uint8_t *r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
+    const u32 one = 1u << RELOC_RESIZE_COEF_BITS;
+    u32 out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x4 + k;
+        if (x < dw) {
+            const int x0 = xofs[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;
+            const u32 a = (u32)xcoef[x];
+            const u32 h0 = r0[x0] * (one - a) + r0[x1] * a;
+            const u32 h1 = r1[x0] * (one - a) + r1[x1] * a;
+            const u32 v = h0 * (one - b) + h1 * b;
+            out |= ((v + (1u << 15)) >> 16) << (8 * k);
+        }
+    }
+    *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;   // padding columns are written as 0
+}
+
+// ---- blur ---------------------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 16;
+__global__ __launch_bounds__(256) void k_blur7(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                               uint8_t *__restrict__ blur)
+{
+    __shared__ uint8_t s_in[(BT_H + 6) * (BT_W + 8)];
+    __shared__ uint16_t s_h[(BT_H + 6) * BT_W];
+    const int l = find_level(tab->blur_tile_base, blockIdx.x);
+    const OrbLevel L = tab->lev[l];
+    const int tile = blockIdx.x - tab->blur_tile_base[l];
+    const int tx = (L.w + BT_W - 1) / BT_W;
+    const int x0 = (tile % tx) * BT_W, y0 = (tile / tx) * BT_H;
+    const uint8_t *src = pyr + L.off;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        const int ry = i / (BT_W + 6), rx = i % (BT_W + 6);
+        const int gy = reflect101(y0 + ry - 3, L.h), gx = reflect101(x0 + rx - 3, L.w);
+        s_in[ry * (BT_W + 8) + rx] = src[(size_t)gy * L.stride + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
+        const int ry = i / BT_W, rx = i % BT_W;
+        const uint8_t *p = s_in + ry * (BT_W + 8) + rx;
+        const u32 s = RELOC_BLUR_K0 * (p[0] + p[6]) + RELOC_BLUR_K1 * (p[1] + p[5]) + RELOC_BLUR_K2 * (p[2] + p[4]) + RELOC_BLUR_K3 * p[3];
+        s_h[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    // 4 output pixels per lane
+    {
+        const int ry = tid / 16, rx4 = (tid % 16) * 4;
+        u32 out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint16_t *p = s_h + ry * BT_W + rx4 + k;
+            const u32 s = RELOC_BLUR_K0 * ((u32)p[0] + p[6 * BT_W]) + RELOC_BLUR_K1 * ((u32)p[BT_W] + p[5 * BT_W]) +
+                          RELOC_BLUR_K2 * ((u32)p[2 * BT_W] + p[4 * BT_W]) + RELOC_BLUR_K3 * (u32)p[3 * BT_W];
+            out |= ((s + (1u << 15)) >> 16) << (8 * k);
+        }
+        const int gy = y0 + ry, gx = x0 + rx4;
+        if (gy < L.h && gx < L.stride) *reinterpret_cast<u32 *>(blur + L.off + (size_t)gy * L.stride + gx) = out;
+    }
+}
+
+// ---- FAST + NMS ---------------------------------------------------------------------------------
+__device__ int fast_score(const uint8_t *p, int stride, int thr)
+{
+    const int c = p[0];
+    int v[16];
+    u32 bright = 0, dark = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = (int)p[c_ring_dy[k] * stride + c_ring_dx[k]] - c;
+        bright |= (u32)(v[k] > thr) << k;
+        dark |= (u32)(v[k] < -thr) << k;
+    }
+    // 9 contiguous set bits on the 16-bit circle
+    auto run9 = [](u32 m) {
+        u32 x = m | (m << 16);
+        u32 y = x & (x >> 1);
+        y &= y >> 2;
+        y &= y >> 4;          // runs of 8
+        y &= x >> 8;          // runs of 9
+        return (y & 0xFFFFu) != 0;
+    };
+    const bool b = run9(bright), d = run9(dark);
+    if (!b && !d) return 0;
+    if (d) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = -v[k];
+    }
+    int m2[16], m4[16], best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m2[k] = min(v[k], v[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int m8 = min(m4[k], m4[(k + 4) & 15]);
+        const int m9 = min(m8, v[(k + 8) & 15]);
+        best = max(best, m9);
+    }
+    return best > thr ? best - 1 : 0;
+}
+
+constexpr int FT = 32;
+__global__ __launch_bounds__(256) void k_fast_nms(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                  uint8_t *__restrict__ nms, int32_t *__restrict__ hist)
+{
+    __shared__ uint8_t s_img[(FT + 8) * (FT + 12)];
+    __shared__ uint8_t s_sc[(FT + 2) * (FT + 4)];
+    __shared__ int s_hist[256];
+    const int l = find_level(tab->fast_tile_base, blockIdx.x);
+    const OrbLevel L = tab->lev[l];
+    const int tile = blockIdx.x - tab->fast_tile_base[l];
+    const int tx = L.stride / FT;
+    const int x0 = (tile % tx) * FT, y0 = (tile / tx) * FT;
+    const int tid = threadIdx.x;
+    const int e = RELOC_ORB_EDGE;
+    uint8_t *out = nms + L.off;
+    // tiles that cannot hold a kept corner only clear their part of the map
+    const bool live = L.quota > 0 && x0 + FT > e && x0 < L.w - e && y0 + FT > e && y0 < L.h - e;
+    if (!live) {
+        const int y = y0 + tid / 8, x = x0 + (tid % 8) * 4;
+        if (y < L.h) *reinterpret_cast<u32 *>(out + (size_t)y * L.stride + x) = 0;
+        return;
+    }
+    s_hist[tid] = 0;
+    const uint8_t *src = pyr + L.off;
+    const int IS = FT + 12;
+    for (int i = tid; i < (FT + 8) * (FT + 8); i += 256) {
+        const int ry = i / (FT + 8), rx = i % (FT + 8);
+        const int gy = min(max(y0 + ry - 4, 0), L.h - 1), gx = min(max(x0 + rx - 4, 0), L.w - 1);
+        s_img[ry * IS + rx] = src[(size_t)gy * L.stride + gx];
+    }
+    __syncthreads();
+    const int SS = FT + 4;
+    for (int i = tid; i < (FT + 2) * (FT + 2); i += 256) {
+        const int ry = i / (FT + 2), rx = i % (FT + 2);
+        const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+        int sc = 0;
+        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3)
+            sc = fast_score(s_img + (ry + 3) * IS + (rx + 3), IS, RELOC_FAST_THRESHOLD);
+        s_sc[ry * SS + rx] = (uint8_t)sc;
+    }
+    __syncthreads();
+    {
+        const int ry = tid / 8, rx4 = (tid % 8) * 4;
+        u32 word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gx = x0 + rx4 + k, gy = y0 + ry;
+            const uint8_t *s = s_sc + (ry + 1) * SS + (rx4 + k + 1);
+            const int c = s[0];
+            if (c && gx >= e && gx < L.w - e && gy >= e && gy < L.h - e && c > s[-1] && c > s[1] && c > s[-SS - 1] &&
+                c > s[-SS] && c > s[-SS + 1] && c > s[SS - 1] && c > s[SS] && c > s[SS + 1]) {
+                word |= (u32)c << (8 * k);
+                atomicAdd(&s_hist[c], 1);
+            }
+        }
+        const int gy = y0 + ry;
+        if (gy < L.h) *reinterpret_cast<u32 *>(out + (size_t)gy * L.stride + x0 + rx4) = word;
+    }
+    __syncthreads();
+    if (s_hist[tid]) atomicAdd(&hist[l * 256 + tid], s_hist[tid]);
+}
+
+// ---- stage 1 cut + Harris -----------------------------------------------------------------------
+__device__ float harris_px(const uint8_t *p, int step)
+{
+    int a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int dy = -3; dy <= 3; ++dy)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) {
+            const uint8_t *q = p + dy * step + dx;
+            const int ix = (q[1] - q[-1]) * 2 + (q[-step + 1] - q[-step - 1]) + (q[step + 1] - q[step - 1]);
+            const int iy = (q[step] - q[-step]) * 2 + (q[step - 1] - q[-step - 1]) + (q[step + 1] - q[-step + 1]);
+            a += ix * ix;
+            b += iy * iy;
+            c += ix * iy;
+        }
+    const float scale = __fdiv_rn(1.f, (float)((1 << 2) * RELOC_HARRIS_BLOCK) * 255.f);
+    const float s2 = __fmul_rn(scale, scale), s3 = __fmul_rn(s2, scale), s4 = __fmul_rn(s3, scale);
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float t1 = __fmul_rn(fa, fb), t2 = __fmul_rn(fc, fc), t3 = __fadd_rn(fa, fb);
+    const float t4 = __fmul_rn(RELOC_HARRIS_K, t3), t5 = __fmul_rn(t4, t3);
+    const float t6 = __fsub_rn(t1, t2), t7 = __fsub_rn(t6, t5);
+    return __fmul_rn(t7, s4);
+}
+
+// cut score from the level's histogram (KeyPointsFilter::retainBest(2*quota) with ties kept, raised
+// while the kept set exceeds RELOC_ORB_STAGE1_CAP).  All 256 threads participate.
+__device__ int stage1_cut(const int32_t *__restrict__ hist_l, int n_keep, int *s_suf, int *s_cut)
+{
+    const int tid = threadIdx.x;
+    s_suf[tid] = hist_l[tid];
+    __syncthreads();
+    // inclusive suffix sum c(s) = sum_{k >= s} hist[k]
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid + d < 256 ? s_suf[tid + d] : 0;
+        __syncthreads();
+        s_suf[tid] += v;
+        __syncthreads();
+    }
+    if (tid == 0) *s_cut = RELOC_FAST_THRESHOLD;
+    __syncthreads();
+    const int total = s_suf[0];
+    if (total > n_keep) {
+        // cut = max{s : c(s) >= n_keep}
+        const int cs = s_suf[tid], cn = tid + 1 < 256 ? s_suf[tid + 1] : 0;
+        if (cs >= n_keep && cn < n_keep) *s_cut = tid;
+    }
+    __syncthreads();
+    const int cut0 = *s_cut;
+    __syncthreads();
+    // smallest s >= cut0 with c(s) <= CAP (or 255)
+    {
+        const int cs = s_suf[tid];
+        const bool ok = tid >= cut0 && (cs <= RELOC_ORB_STAGE1_CAP || tid == 255);
+        const bool prev_ok = tid > cut0 && (s_suf[tid - 1] <= RELOC_ORB_STAGE1_CAP);
+        if (ok && !prev_ok) *s_cut = tid;
+    }
+    __syncthreads();
+    return *s_cut;
+}
+
+__global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                const uint8_t *__restrict__ nms, const int32_t *__restrict__ hist,
+                                                int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
+                                                float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
+{
+    __shared__ int s_suf[256];
+    __shared__ int s_cut;
+    const int l = find_level(tab->flat_base, blockIdx.x);
+    const OrbLevel L = tab->lev[l];
+    if (L.quota <= 0 || L.w <= 2 * RELOC_ORB_EDGE || L.h <= 2 * RELOC_ORB_EDGE) return;
+    const int cut = stage1_cut(hist + l * 256, 2 * L.quota, s_suf, &s_cut);
+    if (dbg_cut && blockIdx.x == tab->flat_base[l] && threadIdx.x == 0) dbg_cut[l] = cut;
+    const int64_t idx0 = ((int64_t)(blockIdx.x - tab->flat_base[l]) * 256 + threadIdx.x) * 16;
+    const int64_t total = (int64_t)L.stride * L.h;
+    if (idx0 >= total) return;
+    const uint4 v = *reinterpret_cast<const uint4 *>(nms + L.off + idx0);
+    const u32 wv[4] = {v.x, v.y, v.z, v.w};
+    if (!(v.x | v.y | v.z | v.w)) return;
+    const uint8_t *img = pyr + L.off;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int s = (wv[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        if (s && s >= cut) {
+            const int64_t idx = idx0 + k;
+            const int y = (int)(idx / L.stride), x = (int)(idx % L.stride);
+            const float r = harris_px(img + (size_t)y * L.stride + x, L.stride);
+            const int pos = atomicAdd(&cand_cnt[l], 1);
+            if (pos < RELOC_ORB_STAGE1_CAP) {
+                cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = ((u32)y << 16) | (u32)x;
+                cand_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = r;
+            }
+        }
+    }
+}
+
+// ---- stage 2: best quota by Harris (ties kept), raster order -----------------------------------
+// One workgroup per level.  Element i is kept iff fewer than `quota` responses are strictly greater
+// (= best quota plus every tie of the quota-th); the kept ones are then placed in raster order by
+// counting smaller keys.  Quadratic in the list length, which is ~2*quota (a few hundred).
+__global__ __launch_bounds__(1024) void k_select(const OrbTable *__restrict__ tab, const int32_t *__restrict__ cand_cnt,
+                                                 const u32 *__restrict__ cand_key, const float *__restrict__ cand_resp,
+                                                 int32_t *__restrict__ kp_cnt, u32 *__restrict__ kp_key,
+                                                 float *__restrict__ kp_resp)
+{
+    __shared__ u32 s_key[RELOC_ORB_STAGE1_CAP];
+    __shared__ float s_resp[RELOC_ORB_STAGE1_CAP];
+    __shared__ u32 s_kidx[RELOC_ORB_STAGE1_CAP];
+    __shared__ int s_nk;
+    const int l = blockIdx.x;
+    const int quota = tab->lev[l].quota;
+    const int M = min(cand_cnt[l], RELOC_ORB_STAGE1_CAP);
+    const int tid = threadIdx.x;
+    if (tid == 0) s_nk = 0;
+    for (int i = tid; i < M; i += 1024) {
+        s_key[i] = cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + i];
+        s_resp[i] = cand_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + i];
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += 1024) {
+        const float r = s_resp[i];
+        int greater = 0;
+        for (int j = 0; j < M; ++j) greater += s_resp[j] > r;
+        if (greater < quota) s_kidx[atomicAdd(&s_nk, 1)] = (u32)i;
+    }
+    __syncthreads();
+    const int K = s_nk;
+    for (int i = tid; i < K; i += 1024) {
+        const u32 src = s_kidx[i];
+        const u32 key = s_key[src];
+        int pos = 0;
+        for (int j = 0; j < K; ++j) pos += s_key[s_kidx[j]] < key;
+        kp_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = key;
+        kp_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = s_resp[src];
+    }
+    if (tid == 0) kp_cnt[l] = K;
+}
+
+// ---- orientation + descriptor -------------------------------------------------------------------
+__device__ float fast_atan2_deg(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax >= ay) {
+        const float c = __fdiv_rn(ay, __fadd_rn(ax, RELOC_ATAN2_EPS));
+        const float c2 = __fmul_rn(c, c);
+        float t = __fadd_rn(__fmul_rn(RELOC_ATAN2_P7, c2), RELOC_ATAN2_P5);
+        t = __fadd_rn(__fmul_rn(t, c2), RELOC_ATAN2_P3);
+        t = __fadd_rn(__fmul_rn(t, c2), RELOC_ATAN2_P1);
+        a = __fmul_rn(t, c);
+    } else {
+        const float c = __fdiv_rn(ax, __fadd_rn(ay, RELOC_ATAN2_EPS));
+        const float c2 = __fmul_rn(c, c);
+        float t = __fadd_rn(__fmul_rn(RELOC_ATAN2_P7, c2), RELOC_ATAN2_P5);
+        t = __fadd_rn(__fmul_rn(t, c2), RELOC_ATAN2_P3);
+        t = __fadd_rn(__fmul_rn(t, c2), RELOC_ATAN2_P1);
+        t = __fmul_rn(t, c);
+        a = __fsub_rn(90.f, t);
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__device__ void sincos_spec(double th, float *s_out, float *c_out)
+{
+    const double PIO2_HI = 1.57079632679489655800e+00;
+    const double PIO2_LO = 6.12323399573676603587e-17;
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double kd = floor(__dadd_rn(__dmul_rn(th, TWO_OVER_PI), 0.5));
+    const int k = (int)kd;
+    double r = __dsub_rn(th, __dmul_rn(kd, PIO2_HI));
+    r = __dsub_rn(r, __dmul_rn(kd, PIO2_LO));
+    const double r2 = __dmul_rn(r, r);
+    const double S[8] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0,
+                         1.0 / 6227020800.0, -1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
+    const double C[8] = {-1.0 / 2.0, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0,
+                         1.0 / 479001600.0, -1.0 / 87178291200.0, 1.0 / 20922789888000.0};
+    double ps = S[7], pc = C[7];
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+        ps = __dadd_rn(__dmul_rn(ps, r2), S[i]);
+        pc = __dadd_rn(__dmul_rn(pc, r2), C[i]);
+    }
+    ps = __dmul_rn(__dadd_rn(__dmul_rn(ps, r2), 1.0), r);
+    pc = __dadd_rn(__dmul_rn(pc, r2), 1.0);
+    double sn, cs;
+    switch (k & 3) {
+    case 0: sn = ps; cs = pc; break;
+    case 1: sn = pc; cs = -ps; break;
+    case 2: sn = -ps; cs = -pc; break;
+    default: sn = -pc; cs = ps; break;
+    }
+    *s_out = (float)sn;
+    *c_out = (float)cs;
+}
+
+// one wave per keypoint; block = 4 waves
+__global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                  const uint8_t *__restrict__ blur, const int32_t *__restrict__ kp_cnt,
+                                                  const u32 *__restrict__ kp_key, const float *__restrict__ kp_resp,
+                                                  int max_feat, float *__restrict__ f_xy, float *__restrict__ f_size,
+                                                  float *__restrict__ f_angle, float *__restrict__ f_resp,
+                                                  int32_t *__restrict__ f_oct, uint8_t *__restrict__ f_desc,
+                                                  int32_t *__restrict__ f_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int base[NLEV + 1];
+    base[0] = 0;
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l) base[l + 1] = base[l] + kp_cnt[l];
+    const int total = base[NLEV];
+    if (g == 0 && lane == 0) *f_count = min(total, max_feat);
+    if (g >= total || g >= max_feat) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < NLEV; ++k) l += g >= base[k];
+    const OrbLevel L = tab->lev[l];
+    const int i = g - base[l];
+    const u32 key = kp_key[(size_t)l * RELOC_ORB_STAGE1_CAP + i];
+    const int x = key & 0xFFFF, y = key >> 16;
+    const uint8_t *center = pyr + L.off + (size_t)y * L.stride + x;
+    // intensity-centroid moments: 31 rows, lane = column offset (-15..15 -> lanes 0..30), two rows at a time
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;            // -15..16 (16 unused)
+        const int half = lane >> 5;                // rows split between the two half-waves
+        for (int vv = half; vv <= 30; vv += 2) {
+            const int v = vv - 15;
+            const int av = v < 0 ? -v : v;
+            if (u <= 15 && (u < 0 ? -u : u) <= c_umax[av]) {
+                const int I = center[v * L.stride + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) {
+            m10 += __shfl_xor(m10, k);
+            m01 += __shfl_xor(m01, k);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    float sn, cs;
+    sincos_spec((double)__fmul_rn(angle, RELOC_DEG2RAD_F), &sn, &cs);
+    const uint8_t *bc = blur + L.off + (size_t)y * L.stride + x;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const signed char *t = c_pattern + 4 * (64 * it + lane);
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float px = (float)t[2 * e], py = (float)t[2 * e + 1];
+            const float rx = __fsub_rn(__fmul_rn(px, cs), __fmul_rn(py, sn));
+            const float ry = __fadd_rn(__fmul_rn(px, sn), __fmul_rn(py, cs));
+            const int ix = (int)rintf(rx), iy = (int)rintf(ry);
+            val[e] = bc[iy * L.stride + ix];
+        }
+        bits[it] = __ballot(val[0] < val[1]);
+    }
+    if (lane < 4) {
+        const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        reinterpret_cast<unsigned long long *>(f_desc + (size_t)g * 32)[lane] = b;
+    }
+    if (lane == 0) {
+        f_xy[2 * g] = __fmul_rn((float)x, L.scale);
+        f_xy[2 * g + 1] = __fmul_rn((float)y, L.scale);
+        f_size[g] = __fmul_rn((float)RELOC_ORB_PATCH, L.scale);
+        f_angle[g] = angle;
+        f_resp[g] = kp_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + i];
+        f_oct[g] = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static void resize_axis(int src_n, int dst_n, int32_t *ofs, int32_t *coef)
+{
+    const double scale = (double)src_n / (double)dst_n;
+    for (int d = 0; d < dst_n; ++d) {
+        double f = ((double)d + 0.5) * scale - 0.5;
+        int s = (int)floor(f);
+        double a = f - (double)s;
+        if (s < 0) { s = 0; a = 0.0; }
+        if (s >= src_n - 1) { s = src_n - 1; a = 0.0; }
+        ofs[d] = s;
+        coef[d] = (int32_t)lrint(a * (double)(1 << RELOC_RESIZE_COEF_BITS));
+    }
+}
+
+static bool g_pattern_uploaded[64] = {};
+
+int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures)
+{
+    if (w > ctx->max_w || h > ctx->max_h) {
+        reloc_set_error("frame %dx%d exceeds the ctx capacity %dx%d", w, h, ctx->max_w, ctx->max_h);
+        return RELOC_E_CAPACITY;
+    }
+    if (ctx->orb_w == w && ctx->orb_h == h && ctx->orb_nfeat == nfeatures) return RELOC_OK;
+    if (!g_pattern_uploaded[ctx->device & 63]) {
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), RELOC_ORB_PATTERN, sizeof(RELOC_ORB_PATTERN)));
+        g_pattern_uploaded[ctx->device & 63] = true;
+    }
+    OrbTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int64_t off = 0;
+    for (int l = 0; l < NLEV; ++l) {
+        const float s = (float)pow(RELOC_ORB_SCALE_FACTOR, (double)l);
+        OrbLevel &L = tab.lev[l];
+        L.scale = s;
+        L.w = (int)lrintf((float)w / s);
+        L.h = (int)lrintf((float)h / s);
+        L.stride = (L.w + 63) / 64 * 64;
+        L.off = off;
+        off += ((int64_t)L.stride * L.h + 255) / 256 * 256;
+    }
+    if (off > ctx->pyr_bytes) { reloc_set_error("pyramid arena too small"); return RELOC_E_CAPACITY; }
+    {
+        const float factor = (float)(1.0 / RELOC_ORB_SCALE_FACTOR);
+        float nper = (float)(nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)NLEV)));
+        int sum = 0;
+        for (int l = 0; l < NLEV - 1; ++l) {
+            tab.lev[l].quota = (int)lrintf(nper);
+            sum += tab.lev[l].quota;
+            nper *= factor;
+        }
+        tab.lev[NLEV - 1].quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    }
+    for (int l = 0; l < NLEV; ++l) {
+        const OrbLevel &L = tab.lev[l];
+        tab.fast_tile_base[l + 1] = tab.fast_tile_base[l] + (L.stride / FT) * ((L.h + FT - 1) / FT);
+        tab.blur_tile_base[l + 1] = tab.blur_tile_base[l] + ((L.w + BT_W - 1) / BT_W) * ((L.h + BT_H - 1) / BT_H);
+        tab.flat_base[l + 1] = tab.flat_base[l] + (int)(((int64_t)L.stride * L.h + 4095) / 4096);
+    }
+    // resize tables
+    const int maxdim = ctx->max_w > ctx->max_h ? ctx->max_w : ctx->max_h;
+    int32_t *host = (int32_t *)malloc(sizeof(int32_t) * (size_t)NLEV * 4 * maxdim);
+    int pos = 0;
+    for (int l = 1; l < NLEV; ++l) {
+        const OrbLevel &S = tab.lev[l - 1], &D = tab.lev[l];
+        tab.rz_off[l][0] = pos; tab.rz_off[l][1] = pos + D.w;
+        resize_axis(S.w, D.w, host + pos, host + pos + D.w);
+        pos += 2 * D.w;
+        tab.rz_off[l][2] = pos; tab.rz_off[l][3] = pos + D.h;
+        resize_axis(S.h, D.h, host + pos, host + pos + D.h);
+        pos += 2 * D.h;
+    }
+    hipError_t e1 = hipMemcpyAsync(ctx->rz_tab, host, sizeof(int32_t) * (size_t)pos, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e2 = hipMemcpyAsync(ctx->orb_const, &tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e3 = hipStreamSynchronize(ctx->stream);
+    free(host);
+    HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
+    memcpy(ctx->lev, tab.lev, sizeof(tab.lev));
+    memcpy(ctx->orb_tab_host, &tab, sizeof(tab));
+    ctx->orb_w = w; ctx->orb_h = h; ctx->orb_nfeat = nfeatures;
+    return RELOC_OK;
+}
+
+// src_dev: channels == 3 -> interleaved frame (gray fused), channels == 1 -> gray plane.
+int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order, int nfeatures)
+{
+    int rc = orb_prepare(ctx, w, h, nfeatures);
+    if (rc) return rc;
+    const OrbTable *tab_h = (const OrbTable *)ctx->orb_tab_host;
+    const OrbTable *tab_d = (const OrbTable *)ctx->orb_const;
+    hipStream_t st = ctx->stream;
+    reloc_prof_begin(ctx, RELOC_PROF_ORB);
+    const OrbLevel &L0 = tab_h->lev[0];
+    if (channels == 3) {
+        hipLaunchKernelGGL(k_gray_l0, dim3((w + 1023) / 1024, h), dim3(256), 0, st, src_dev, w, h, stride, order,
+                           ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
+    } else {
+        hipLaunchKernelGGL(k_clear_counters, dim3(1), dim3(256), 0, st, ctx->hist, ctx->cand_cnt);
+        HIP_TRY(hipMemcpy2DAsync(ctx->pyr + L0.off, L0.stride, src_dev, stride, w, h, hipMemcpyDeviceToDevice, st));
+    }
+    for (int l = 1; l < NLEV; ++l) {
+        const OrbLevel &S = tab_h->lev[l - 1], &D = tab_h->lev[l];
+        hipLaunchKernelGGL(k_resize, dim3((D.stride / 4 + 255) / 256, D.h), dim3(256), 0, st, ctx->pyr + S.off, S.w, S.h,
+                           S.stride, ctx->pyr + D.off, D.w, D.h, D.stride, ctx->rz_tab + tab_h->rz_off[l][0],
+                           ctx->rz_tab + tab_h->rz_off[l][1], ctx->rz_tab + tab_h->rz_off[l][2],
+                           ctx->rz_tab + tab_h->rz_off[l][3]);
+    }
+    hipLaunchKernelGGL(k_blur7, dim3(tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->blur);
+    hipLaunchKernelGGL(k_fast_nms, dim3(tab_h->fast_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->nms, ctx->hist);
+    hipLaunchKernelGGL(k_harris, dim3(tab_h->flat_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->nms, ctx->hist,
+                       ctx->cand_cnt, ctx->cand_key, ctx->cand_resp, ctx->dbg_cut);
+    hipLaunchKernelGGL(k_select, dim3(NLEV), dim3(1024), 0, st, tab_d, ctx->cand_cnt,
+                       ctx->cand_key, ctx->cand_resp, ctx->kp_cnt, ctx->kp_key, ctx->kp_resp);
+    hipLaunchKernelGGL(k_describe, dim3((ctx->max_feat + 3) / 4), dim3(256), 0, st, tab_d, ctx->pyr, ctx->blur, ctx->kp_cnt,
+                       ctx->kp_key, ctx->kp_resp, ctx->max_feat, ctx->f_xy, ctx->f_size, ctx->f_angle, ctx->f_resp,
+                       ctx->f_oct, ctx->f_desc, ctx->f_count);
+    reloc_prof_end(ctx, RELOC_PROF_ORB);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+RELOC_API int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, int stride, int order, uint8_t *gray)
+{
+    ARG_CHECK(ctx && img && gray && w > 0 && h > 0 && stride >= 3 * w, "reloc_gray_u8");
+    if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
+    void *dout;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)w * h, &dout))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(ctx->frame_img, (size_t)w * 3, img, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gray_plain, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, ctx->frame_img, w, h, w * 3, order,
+                       (uint8_t *)dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(gray, dout, (size_t)w * h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_orb_frame_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int stride, int order, int nfeatures)
+{
+    ARG_CHECK(ctx && img_dev && w >= 64 && h >= 64 && stride >= 3 * w && nfeatures > 0, "reloc_orb_frame_dev");
+    return orb_run_dev(ctx, img_dev, w, h, stride, 3, order, nfeatures);
+}
+
+RELOC_API const uint8_t *reloc_frame_desc_dev(reloc_ctx *ctx) { return ctx ? ctx->f_desc : nullptr; }
+RELOC_API const float *reloc_frame_xy_dev(reloc_ctx *ctx) { return ctx ? ctx->f_xy : nullptr; }
+RELOC_API const int32_t *reloc_frame_count_dev(reloc_ctx *ctx) { return ctx ? ctx->f_count : nullptr; }
+
+RELOC_API int reloc_orb_detect_compute(reloc_ctx *ctx, const uint8_t *gray, int w, int h, int stride, int nfeatures,
+                                       float *xy, float *size, float *angle, float *response, int32_t *octave,
+                                       uint8_t *desc, int32_t *n_out)
+{
+    ARG_CHECK(ctx && gray && n_out && w > 0 && h > 0 && stride >= w && nfeatures > 0, "reloc_orb_detect_compute");
+    *n_out = 0;
+    if (w < 63 || h < 63) return RELOC_OK;   // no level is wider than the 31-pixel edge margin on both sides
+    if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
+    HIP_TRY(hipMemcpy2DAsync(ctx->frame_img, w, gray, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    int rc = orb_run_dev(ctx, ctx->frame_img, w, h, w, 1, 0, nfeatures);
+    if (rc) return rc;
+    int32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, ctx->f_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        if (xy) HIP_TRY(hipMemcpyAsync(xy, ctx->f_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (size) HIP_TRY(hipMemcpyAsync(size, ctx->f_size, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (angle) HIP_TRY(hipMemcpyAsync(angle, ctx->f_angle, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (response) HIP_TRY(hipMemcpyAsync(response, ctx->f_resp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (octave) HIP_TRY(hipMemcpyAsync(octave, ctx->f_oct, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, ctx->f_desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_frame_debug_plane(reloc_ctx *ctx, int what, int level, uint8_t *out, int32_t *w, int32_t *h)
+{
+    ARG_CHECK(ctx && out && w && h && what >= 0 && what <= 2 && level >= 0 && level < NLEV, "reloc_frame_debug_plane");
+    if (!ctx->orb_w) { reloc_set_error("no frame processed yet"); return RELOC_E_STATE; }
+    const OrbLevel &L = ctx->lev[level];
+    const uint8_t *src = (what == 0 ? ctx->pyr : what == 1 ? ctx->blur : ctx->nms) + L.off;
+    HIP_TRY(hipMemcpy2DAsync(out, L.w, src, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *w = L.w;
+    *h = L.h;
+    return RELOC_OK;
+}

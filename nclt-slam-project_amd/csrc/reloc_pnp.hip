@@ -1,0 +1,616 @@
+// reloc_pnp.hip -- batched PnP-RANSAC on gfx950: hypothesis generation, reprojection scoring,
+// adaptive-cap selection and Levenberg-Marquardt refinement, for up to MAX_CAND candidate records
+// per launch.
+//
+// Serves cv2.solvePnPRansac(obj, img, K, DIST, iterationsCount=200, reprojectionError=3.0,
+//                           flags=SOLVEPNP_ITERATIVE)                    (reference M:342-346, S:78-82)
+// and the mean inlier reprojection error of M:353-356.
+//
+// Three kernels per batch:
+//   k_pnp_hyp     one lane per (candidate, hypothesis): counter-based sampler, P3P on three points,
+//                 fourth point picks the root.  IEEE double add/sub/mul/div/sqrt only, no FMA, so the
+//                 pose list is bit-identical to the specification.
+//   k_pnp_score   one wave per (candidate, hypothesis): reprojection error of every correspondence,
+//                 inlier count by ballot.  This is the data-parallel bulk (H x m projections).
+//   k_pnp_finish  one wave per candidate: sequential adaptive-cap scan over the counts (lane 0),
+//                 inlier list by ballot compaction, LM refinement with the 6x6 normal equations
+//                 summed across the wave in fp64, Rodrigues log, mean inlier error.
+#include "reloc_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// deterministic helpers (mirror the arithmetic order of the specification exactly)
+__device__ __forceinline__ uint64_t sm64_next(uint64_t &s)
+{
+    s += RELOC_RNG_GOLDEN;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * RELOC_RNG_MUL1;
+    z = (z ^ (z >> 27)) * RELOC_RNG_MUL2;
+    return z ^ (z >> 31);
+}
+
+__device__ bool pnp_sample(uint64_t seed, int h, int m, int idx[4])
+{
+    if (m < RELOC_PNP_SAMPLE) return false;
+    uint64_t s = seed ^ ((uint64_t)(h + 1) * RELOC_RNG_MUL1);
+    for (int k = 0; k < RELOC_PNP_SAMPLE; ++k) {
+        for (;;) {
+            const uint64_t z = sm64_next(s);
+            const int c = (int)(((z >> 32) * (uint64_t)m) >> 32);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= idx[j] == c;
+            if (!dup) { idx[k] = c; break; }
+        }
+    }
+    return true;
+}
+
+__device__ double log_spec(double x)
+{
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440) { m = m * 2.0; e -= 1; }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
+    double p = 1.0 / 23.0;
+    for (int k = 21; k >= 1; k -= 2) { p = p * z2; p = p + 1.0 / (double)k; }
+    p = p * z; p = p * 2.0;
+    return (double)e * 0.69314718055994530942 + p;
+}
+
+__device__ int ransac_update_iters(double conf, double outlier_ratio, int max_iters)
+{
+    const double DBL_MIN_ = 2.2250738585072014e-308;
+    const double p = conf < 0 ? 0 : (conf > 1 ? 1 : conf);
+    const double ep = outlier_ratio < 0 ? 0 : (outlier_ratio > 1 ? 1 : outlier_ratio);
+    double num = 1.0 - p; if (num < DBL_MIN_) num = DBL_MIN_;
+    const double w = 1.0 - ep, w2 = w * w, w4 = w2 * w2;
+    double den = 1.0 - w4;
+    if (den < DBL_MIN_) return 0;
+    num = log_spec(num);
+    den = log_spec(den);
+    if (den >= 0 || -num >= (double)max_iters * (-den)) return max_iters;
+    return (int)rint(num / den);
+}
+
+__device__ double cubic_pos_root(double c2, double c1, double c0)
+{
+    double lo = 0.0, hi = 1.0 + fabs(c2);
+    if (fabs(c1) + 1.0 > hi) hi = fabs(c1) + 1.0;
+    if (fabs(c0) + 1.0 > hi) hi = fabs(c0) + 1.0;
+    double x = hi;
+    for (int it = 0; it < 80; ++it) {
+        const double g = ((x + c2) * x + c1) * x + c0;
+        const double dg = (3.0 * x + 2.0 * c2) * x + c1;
+        if (g > 0) hi = x; else lo = x;
+        double xn = x - g / dg;
+        if (!(dg != 0.0) || !(xn > lo) || !(xn < hi)) xn = 0.5 * (lo + hi);
+        if (xn == x) break;
+        x = xn;
+    }
+    return x;
+}
+
+__device__ int quartic_real_roots(const double A[5], double roots[4])
+{
+    double amax = 0;
+    for (int i = 0; i < 5; ++i) if (fabs(A[i]) > amax) amax = fabs(A[i]);
+    if (!(fabs(A[4]) > 1e-12 * amax) || !(amax > 0)) return 0;
+    const double a = A[3] / A[4], b = A[2] / A[4], c = A[1] / A[4], d = A[0] / A[4];
+    const double a2 = a * a;
+    const double p = b - 0.375 * a2;
+    const double q = c - 0.5 * a * b + 0.125 * a2 * a;
+    const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    double y[4];
+    int n = 0;
+    const double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
+    if (fabs(q) <= 1e-14 * scale * sqrt(scale)) {
+        const double disc = p * p - 4.0 * r;
+        if (disc >= 0) {
+            const double sd = sqrt(disc);
+            const double z1 = 0.5 * (-p + sd), z2 = 0.5 * (-p - sd);
+            if (z1 >= 0) { const double s = sqrt(z1); y[n++] = s; y[n++] = -s; }
+            if (z2 >= 0) { const double s = sqrt(z2); y[n++] = s; y[n++] = -s; }
+        }
+    } else {
+        const double m = cubic_pos_root(p, 0.25 * p * p - r, -0.125 * q * q);
+        if (!(m > 0)) return 0;
+        const double s = sqrt(2.0 * m);
+        const double t = q / (2.0 * s);
+        const double h = 0.5 * p + m;
+        const double d1 = s * s - 4.0 * (h - t);
+        const double d2 = s * s - 4.0 * (h + t);
+        if (d1 >= 0) { const double sd = sqrt(d1); y[n++] = 0.5 * (-s + sd); y[n++] = 0.5 * (-s - sd); }
+        if (d2 >= 0) { const double sd = sqrt(d2); y[n++] = 0.5 * (s + sd); y[n++] = 0.5 * (s - sd); }
+    }
+    for (int i = 0; i < n; ++i) {
+        double v = y[i] - 0.25 * a;
+        for (int it = 0; it < 3; ++it) {
+            const double f = (((A[4] * v + A[3]) * v + A[2]) * v + A[1]) * v + A[0];
+            const double df = ((4.0 * A[4] * v + 3.0 * A[3]) * v + 2.0 * A[2]) * v + A[1];
+            if (df != 0.0) { const double vn = v - f / df; if (vn == vn) v = vn; }
+        }
+        roots[i] = v;
+    }
+    return n;
+}
+
+__device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ bool unit3(double *a)
+{
+    const double n = sqrt(dot3(a, a));
+    if (!(n > 1e-300)) return false;
+    a[0] /= n; a[1] /= n; a[2] /= n;
+    return true;
+}
+__device__ bool frame3(const double *p0, const double *p1, const double *p2, double F[9])
+{
+    double e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    double w[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    double e3[3], e2[3];
+    if (!unit3(e1)) return false;
+    cross3(e1, w, e3);
+    if (!unit3(e3)) return false;
+    cross3(e3, e1, e2);
+    for (int i = 0; i < 3; ++i) { F[3 * i] = e1[i]; F[3 * i + 1] = e2[i]; F[3 * i + 2] = e3[i]; }
+    return true;
+}
+
+__device__ int p3p(const double P[9], const double xn[6], double Rt[48])
+{
+    double f[3][3];
+    for (int i = 0; i < 3; ++i) {
+        f[i][0] = xn[2 * i]; f[i][1] = xn[2 * i + 1]; f[i][2] = 1.0;
+        if (!unit3(f[i])) return 0;
+    }
+    double d12[3], d02[3], d01[3];
+    for (int k = 0; k < 3; ++k) {
+        d12[k] = P[3 + k] - P[6 + k];
+        d02[k] = P[k] - P[6 + k];
+        d01[k] = P[k] - P[3 + k];
+    }
+    const double a2 = dot3(d12, d12), b2 = dot3(d02, d02), c2 = dot3(d01, d01);
+    if (!(a2 > 0) || !(b2 > 0) || !(c2 > 0)) return 0;
+    const double ca = dot3(f[1], f[2]), cb = dot3(f[0], f[2]), cg = dot3(f[0], f[1]);
+    const double K = (a2 - c2) / b2, q = c2 / b2;
+    const double N[3] = {1.0 + K, -2.0 * K * cb, K - 1.0};
+    const double D[2] = {2.0 * cg, -2.0 * ca};
+    const double NN[5] = {N[0] * N[0], 2.0 * N[0] * N[1], 2.0 * N[0] * N[2] + N[1] * N[1], 2.0 * N[1] * N[2], N[2] * N[2]};
+    const double ND[4] = {N[0] * D[0], N[0] * D[1] + N[1] * D[0], N[1] * D[1] + N[2] * D[0], N[2] * D[1]};
+    const double DD[3] = {D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1]};
+    const double W[3] = {1.0 - q, 2.0 * q * cb, -q};
+    const double DW[5] = {DD[0] * W[0], DD[0] * W[1] + DD[1] * W[0], DD[0] * W[2] + DD[1] * W[1] + DD[2] * W[0],
+                          DD[1] * W[2] + DD[2] * W[1], DD[2] * W[2]};
+    double A[5];
+    for (int i = 0; i < 5; ++i) A[i] = NN[i] + DW[i];
+    for (int i = 0; i < 4; ++i) A[i] -= 2.0 * cg * ND[i];
+    double roots[4];
+    const int nr = quartic_real_roots(A, roots);
+    double Fp[9];
+    if (!frame3(P, P + 3, P + 6, Fp)) return 0;
+    int ns = 0;
+    for (int i = 0; i < nr; ++i) {
+        const double v = roots[i];
+        if (!(v > 0)) continue;
+        const double Dv = D[1] * v + D[0];
+        if (!(fabs(Dv) > 1e-12)) continue;
+        const double u = ((N[2] * v + N[1]) * v + N[0]) / Dv;
+        if (!(u > 0)) continue;
+        const double den = 1.0 + v * v - 2.0 * v * cb;
+        if (!(den > 1e-300)) continue;
+        const double s0 = sqrt(b2 / den), s1 = u * s0, s2 = v * s0;
+        double C[3][3];
+        for (int k = 0; k < 3; ++k) { C[0][k] = s0 * f[0][k]; C[1][k] = s1 * f[1][k]; C[2][k] = s2 * f[2][k]; }
+        double Fc[9];
+        if (!frame3(C[0], C[1], C[2], Fc)) continue;
+        double *R = Rt + 12 * ns, *t = R + 9;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                R[3 * r + c] = Fc[3 * r] * Fp[3 * c] + Fc[3 * r + 1] * Fp[3 * c + 1] + Fc[3 * r + 2] * Fp[3 * c + 2];
+        for (int r = 0; r < 3; ++r) t[r] = C[0][r] - (R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2]);
+        bool ok = true;
+        for (int k = 0; k < 12; ++k) ok &= R[k] == R[k];
+        if (ok) ++ns;
+    }
+    return ns;
+}
+
+__device__ __forceinline__ double reproj_err2(const double *Rt, const double K4[4], const float *obj, const float *img)
+{
+    const double X = obj[0], Y = obj[1], Z = obj[2];
+    const double x = ((Rt[0] * X + Rt[1] * Y) + Rt[2] * Z) + Rt[9];
+    const double y = ((Rt[3] * X + Rt[4] * Y) + Rt[5] * Z) + Rt[10];
+    const double z = ((Rt[6] * X + Rt[7] * Y) + Rt[8] * Z) + Rt[11];
+    const double u = K4[0] * (x / z) + K4[2];
+    const double v = K4[1] * (y / z) + K4[3];
+    const double du = u - (double)img[0], dv = v - (double)img[1];
+    return du * du + dv * dv;
+}
+
+struct PnpParams {
+    double K4[4];
+    double conf;
+    double thr2;
+    uint64_t seed;
+    int iters;
+    int stride;      // rows per candidate in obj/img/inlier arrays
+    int min_m;       // fewer correspondences than this => no model (matcher gate M:330, or 4)
+};
+
+// grid (ceil(iters/64), n_cand_max), block 64
+__global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
+                                                const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
+{
+    const int c = blockIdx.y;
+    if (n_cand_p && c >= *n_cand_p) return;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= prm.iters) return;
+    const int m = m_arr[c];
+    const float *o = obj + (size_t)c * prm.stride * 3;
+    const float *im = img + (size_t)c * prm.stride * 2;
+    double *out = Rt_out + ((size_t)c * MAX_HYP + h) * 12;
+    int32_t *cn = cnt + (size_t)c * MAX_HYP + h;
+    int idx[4];
+    if (m < prm.min_m || !pnp_sample(prm.seed, h, m, idx)) { *cn = -1; return; }
+    double P[9], xn[6], sols[48];
+    for (int k = 0; k < 3; ++k) {
+        for (int e = 0; e < 3; ++e) P[3 * k + e] = o[3 * idx[k] + e];
+        xn[2 * k] = ((double)im[2 * idx[k]] - prm.K4[2]) / prm.K4[0];
+        xn[2 * k + 1] = ((double)im[2 * idx[k] + 1] - prm.K4[3]) / prm.K4[1];
+    }
+    const int ns = p3p(P, xn, sols);
+    int best = -1;
+    double beste = 0;
+    for (int s = 0; s < ns; ++s) {
+        const double e = reproj_err2(sols + 12 * s, prm.K4, o + 3 * idx[3], im + 2 * idx[3]);
+        if (!(e == e)) continue;
+        if (best < 0 || e < beste) { best = s; beste = e; }
+    }
+    if (best < 0) { *cn = -1; return; }
+    for (int k = 0; k < 12; ++k) out[k] = sols[12 * best + k];
+    *cn = 0;
+}
+
+// grid (iters, n_cand_max), block 64: one wave scores one hypothesis
+__global__ __launch_bounds__(64) void k_pnp_score(const float *__restrict__ obj, const float *__restrict__ img,
+                                                  const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                  PnpParams prm, const double *__restrict__ Rt_in,
+                                                  int32_t *__restrict__ cnt, uint8_t *__restrict__ mask, int hyp_stride)
+{
+    const int c = blockIdx.y;
+    if (n_cand_p && c >= *n_cand_p) return;
+    const int h = blockIdx.x;
+    int32_t *cn = cnt + (size_t)c * hyp_stride + h;
+    if (*cn < 0) return;
+    const int m = m_arr[c];
+    const float *o = obj + (size_t)c * prm.stride * 3;
+    const float *im = img + (size_t)c * prm.stride * 2;
+    double Rt[12];
+    for (int k = 0; k < 12; ++k) Rt[k] = Rt_in[((size_t)c * hyp_stride + h) * 12 + k];
+    int count = 0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + threadIdx.x;
+        bool in = false;
+        if (i < m) in = reproj_err2(Rt, prm.K4, o + 3 * i, im + 2 * i) <= prm.thr2;
+        if (mask && i < m) mask[((size_t)c * hyp_stride + h) * m + i] = (uint8_t)in;
+        count += __popcll(__ballot(in));
+    }
+    if (threadIdx.x == 0) *cn = count;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ void rodrigues_exp(const double w[3], double R[9])
+{
+    const double th2 = dot3(w, w), th = sqrt(th2);
+    double A, B;
+    if (th < 1e-6) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; }
+    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; }
+    const double x = w[0], y = w[1], z = w[2];
+    R[0] = 1.0 - B * (y * y + z * z); R[1] = -A * z + B * x * y;      R[2] = A * y + B * x * z;
+    R[3] = A * z + B * x * y;        R[4] = 1.0 - B * (x * x + z * z); R[5] = -A * x + B * y * z;
+    R[6] = -A * y + B * x * z;       R[7] = A * x + B * y * z;        R[8] = 1.0 - B * (x * x + y * y);
+}
+
+__device__ void rodrigues_log(const double R[9], double rvec[3])
+{
+    const double tr = R[0] + R[4] + R[8];
+    double c = 0.5 * (tr - 1.0);
+    if (c > 1) c = 1;
+    if (c < -1) c = -1;
+    const double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    const double s = 0.5 * sqrt(dot3(ax, ax));
+    const double th = atan2(s, c);
+    if (s < 1e-9) {
+        if (c > 0) { rvec[0] = 0.5 * ax[0]; rvec[1] = 0.5 * ax[1]; rvec[2] = 0.5 * ax[2]; return; }
+        double xx = sqrt(fmax((R[0] + 1.0) * 0.5, 0.0)), yy = sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)), zz = sqrt(fmax((R[8] + 1.0) * 0.5, 0.0));
+        if (xx >= yy && xx >= zz) { if (R[1] < 0) yy = -yy; if (R[2] < 0) zz = -zz; }
+        else if (yy >= zz) { if (R[1] < 0) xx = -xx; if (R[5] < 0) zz = -zz; }
+        else { if (R[2] < 0) xx = -xx; if (R[5] < 0) yy = -yy; }
+        const double n = sqrt(xx * xx + yy * yy + zz * zz);
+        rvec[0] = th * xx / n; rvec[1] = th * yy / n; rvec[2] = th * zz / n;
+        return;
+    }
+    const double k = th / (2.0 * s);
+    rvec[0] = k * ax[0]; rvec[1] = k * ax[1]; rvec[2] = k * ax[2];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k);
+    return v;
+}
+
+// Normal equations of the reprojection cost over the selected points, summed across the wave.
+// H: upper triangle (21 values, row-major a<=b), g: 6, returns the cost; every lane gets the sums.
+__device__ double lm_normal_wave(const float *obj, const float *img, const int32_t *sel, int n, const double *Rt,
+                                 const double K4[4], double H[21], double g[6])
+{
+    double cost = 0;
+    for (int k = 0; k < 21; ++k) H[k] = 0;
+    for (int k = 0; k < 6; ++k) g[k] = 0;
+    for (int kk = threadIdx.x; kk < n; kk += 64) {
+        const int i = sel[kk];
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        const double xr = Rt[0] * X + Rt[1] * Y + Rt[2] * Z;
+        const double yr = Rt[3] * X + Rt[4] * Y + Rt[5] * Z;
+        const double zr = Rt[6] * X + Rt[7] * Y + Rt[8] * Z;
+        const double x = xr + Rt[9], y = yr + Rt[10], z = zr + Rt[11];
+        const double iz = 1.0 / z;
+        const double ru = K4[0] * x * iz + K4[2] - (double)img[2 * i];
+        const double rv = K4[1] * y * iz + K4[3] - (double)img[2 * i + 1];
+        const double ux = K4[0] * iz, uz = -K4[0] * x * iz * iz;
+        const double vy = K4[1] * iz, vz = -K4[1] * y * iz * iz;
+        double Ju[6], Jv[6];
+        Ju[0] = uz * yr;            Ju[1] = ux * zr - uz * xr; Ju[2] = -ux * yr;
+        Jv[0] = -vy * zr + vz * yr; Jv[1] = -vz * xr;          Jv[2] = vy * xr;
+        Ju[3] = ux; Ju[4] = 0;  Ju[5] = uz;
+        Jv[3] = 0;  Jv[4] = vy; Jv[5] = vz;
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            g[a] += Ju[a] * ru + Jv[a] * rv;
+#pragma unroll
+            for (int b = a; b < 6; ++b) H[o++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        }
+        cost += ru * ru + rv * rv;
+    }
+    for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
+    for (int k = 0; k < 6; ++k) g[k] = wave_sum(g[k]);
+    return wave_sum(cost);
+}
+
+__device__ bool chol_solve6(const double Ain[36], const double b[6], double x[6])
+{
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = Ain[6 * i + j];
+            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) { if (!(s > 0)) return false; L[6 * i + i] = sqrt(s); }
+            else L[6 * i + j] = s / L[6 * j + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    return true;
+}
+
+// grid n_cand_max, block 64
+__global__ __launch_bounds__(64) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
+                                                   const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                   PnpParams prm, const double *__restrict__ Rt_all,
+                                                   const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
+                                                   PnpOut *__restrict__ out)
+{
+    const int c = blockIdx.x;
+    if (n_cand_p && c >= *n_cand_p) return;
+    const int lane = threadIdx.x;
+    const int m = m_arr[c];
+    const float *o = obj + (size_t)c * prm.stride * 3;
+    const float *im = img + (size_t)c * prm.stride * 2;
+    int32_t *inl = inl_out + (size_t)c * prm.stride;
+    PnpOut &po = out[c];
+    __shared__ int s_best;
+    // adaptive-cap RANSAC decision (sequential by definition; the counts are tiny)
+    if (lane == 0) {
+        int best = -1;
+        if (m >= prm.min_m) {
+            int niters = prm.iters, best_count = RELOC_PNP_SAMPLE - 1;
+            for (int h = 0; h < prm.iters && h < niters; ++h) {
+                const int ch = cnt[(size_t)c * MAX_HYP + h];
+                if (ch > best_count) {
+                    best = h;
+                    best_count = ch;
+                    niters = ransac_update_iters(prm.conf, (double)(m - ch) / (double)m, niters);
+                }
+            }
+        }
+        s_best = best;
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) {
+        if (lane == 0) { po.ok = 0; po.n_inl = 0; po.best_h = -1; po.n_matches = m; po.reproj_mean = 0; }
+        return;
+    }
+    double Rt[12];
+    for (int k = 0; k < 12; ++k) Rt[k] = Rt_all[((size_t)c * MAX_HYP + best) * 12 + k];
+    // inlier list (ascending) by ballot compaction
+    int n = 0;
+    for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < m) in = reproj_err2(Rt, prm.K4, o + 3 * i, im + 2 * i) <= prm.thr2;
+        const unsigned long long bal = __ballot(in);
+        if (in) inl[n + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        n += __popcll(bal);
+    }
+    __syncthreads();
+    // Levenberg-Marquardt on the inliers, left-multiplied rotation increment
+    double H[21], g[6], Hn[21], gn[6];
+    double cost = lm_normal_wave(o, im, inl, n, Rt, prm.K4, H, g);
+    double lambda = RELOC_LM_LAMBDA0;
+    for (int trial = 0; trial < RELOC_LM_MAX_TRIALS; ++trial) {
+        double A[36], rhs[6], dx[6];
+        {
+            int oo = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) { A[6 * a + b] = H[oo]; A[6 * b + a] = H[oo]; ++oo; }
+        }
+        for (int a = 0; a < 6; ++a) {
+            const double d = A[6 * a + a];
+            A[6 * a + a] += lambda * (d > 1e-300 ? d : 1e-300);
+            rhs[a] = -g[a];
+        }
+        if (!chol_solve6(A, rhs, dx)) { lambda *= 10.0; continue; }
+        double dR[9], Rn[12];
+        rodrigues_exp(dx, dR);
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc)
+                Rn[3 * r + cc] = dR[3 * r] * Rt[cc] + dR[3 * r + 1] * Rt[3 + cc] + dR[3 * r + 2] * Rt[6 + cc];
+        for (int k = 0; k < 3; ++k) Rn[9 + k] = Rt[9 + k] + dx[3 + k];
+        const double cn = lm_normal_wave(o, im, inl, n, Rn, prm.K4, Hn, gn);
+        double step = 0;
+        for (int a = 0; a < 6; ++a) if (fabs(dx[a]) > step) step = fabs(dx[a]);
+        if (cn == cn && cn <= cost) {
+            for (int k = 0; k < 12; ++k) Rt[k] = Rn[k];
+            for (int k = 0; k < 21; ++k) H[k] = Hn[k];
+            for (int k = 0; k < 6; ++k) g[k] = gn[k];
+            cost = cn;
+            lambda *= 0.1; if (lambda < 1e-12) lambda = 1e-12;
+            if (step < RELOC_LM_STEP_EPS) break;
+        } else {
+            lambda *= 10.0;
+            if (step < RELOC_LM_STEP_EPS) break;
+        }
+    }
+    // mean inlier reprojection error under the refined pose (reference M:353-356)
+    double esum = 0;
+    for (int kk = lane; kk < n; kk += 64) {
+        const int i = inl[kk];
+        esum += sqrt(reproj_err2(Rt, prm.K4, o + 3 * i, im + 2 * i));
+    }
+    esum = wave_sum(esum);
+    if (lane == 0) {
+        for (int k = 0; k < 12; ++k) po.Rt[k] = Rt[k];
+        rodrigues_log(Rt, po.rvec);
+        po.reproj_mean = n > 0 ? esum / (double)n : 0.0;
+        po.ok = 1;
+        po.n_inl = n;
+        po.best_h = best;
+        po.n_matches = m;
+    }
+}
+
+static PnpParams make_params(const double K4[4], int iters, float thr_px, double conf, uint64_t seed, int stride,
+                             int min_m)
+{
+    PnpParams p;
+    for (int k = 0; k < 4; ++k) p.K4[k] = K4[k];
+    p.conf = conf;
+    p.thr2 = (double)thr_px * (double)thr_px;
+    p.seed = seed;
+    p.iters = iters;
+    p.stride = stride;
+    p.min_m = min_m < RELOC_PNP_SAMPLE ? RELOC_PNP_SAMPLE : min_m;
+    return p;
+}
+
+int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4], int iters,
+                       float thr_px, double conf, uint64_t seed, int min_m)
+{
+    if (n_cand_max <= 0) return RELOC_OK;
+    if (n_cand_max > MAX_CAND || iters < 1 || iters > MAX_HYP) {
+        reloc_set_error("pnp: n_cand %d (max %d) iters %d (max %d)", n_cand_max, MAX_CAND, iters, MAX_HYP);
+        return RELOC_E_CAPACITY;
+    }
+    const PnpParams prm = make_params(K4, iters, thr_px, conf, seed, MAX_REC_ROWS, min_m);
+    reloc_prof_begin(ctx, RELOC_PROF_PNP);
+    hipLaunchKernelGGL(k_pnp_hyp, dim3((iters + 63) / 64, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img,
+                       ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt);
+    hipLaunchKernelGGL(k_pnp_score, dim3(iters, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
+                       n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, (uint8_t *)nullptr, MAX_HYP);
+    hipLaunchKernelGGL(k_pnp_finish, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
+                       n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
+    reloc_prof_end(ctx, RELOC_PROF_PNP);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+RELOC_API int reloc_pnp_score(reloc_ctx *ctx, const float *obj, const float *img, int m, const double *Rt, int H,
+                              const double K4[4], float thr_px, int32_t *inlier_count, uint8_t *mask)
+{
+    ARG_CHECK(ctx && m >= 0 && H >= 0 && K4 && (H == 0 || (Rt && inlier_count)) && (m == 0 || (obj && img)),
+              "reloc_pnp_score");
+    if (H == 0) return RELOC_OK;
+    if (m == 0) { for (int h = 0; h < H; ++h) inlier_count[h] = 0; return RELOC_OK; }
+    if (H > 65535) { reloc_set_error("pnp_score: more than 65535 hypotheses"); return RELOC_E_CAPACITY; }
+    void *dobj, *dimg, *drt, *dcnt, *dmask = nullptr, *dm;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)m * 12, &dobj))) return rc;
+    if ((rc = reloc_scratch(ctx, 1, (int64_t)m * 8, &dimg))) return rc;
+    if ((rc = reloc_scratch(ctx, 2, (int64_t)H * 96, &drt))) return rc;
+    if ((rc = reloc_scratch(ctx, 3, (int64_t)H * 4 + 16, &dcnt))) return rc;
+    if (mask && (rc = reloc_scratch(ctx, 4, (int64_t)H * m, &dmask))) return rc;
+    dm = (char *)dcnt + (int64_t)H * 4;
+    HIP_TRY(hipMemcpyAsync(dobj, obj, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dimg, img, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(drt, Rt, (size_t)H * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(dcnt, 0, (size_t)H * 4, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dm, &m, 4, hipMemcpyHostToDevice, ctx->stream));
+    const PnpParams prm = make_params(K4, H, thr_px, 0.99, 0, m, 0);
+    hipLaunchKernelGGL(k_pnp_score, dim3(H, 1), dim3(64), 0, ctx->stream, (const float *)dobj, (const float *)dimg,
+                       (const int32_t *)dm, (const int32_t *)nullptr, prm, (const double *)drt, (int32_t *)dcnt,
+                       (uint8_t *)dmask, H);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(inlier_count, dcnt, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) HIP_TRY(hipMemcpyAsync(mask, dmask, (size_t)H * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *img, int m, const double K4[4], int iters,
+                               float thr_px, double conf, uint64_t seed, double rvec[3], double tvec[3],
+                               int32_t *inliers, int32_t *n_inl, int32_t *ok)
+{
+    ARG_CHECK(ctx && m >= 0 && K4 && rvec && tvec && n_inl && ok && (m == 0 || (obj && img && inliers)),
+              "reloc_pnp_ransac");
+    ARG_CHECK(iters >= 1 && iters <= MAX_HYP, "iterationsCount must be in [1, 256]");
+    *ok = 0;
+    *n_inl = 0;
+    if (m < RELOC_PNP_SAMPLE) return RELOC_OK;
+    if (m > MAX_REC_ROWS) { reloc_set_error("solvePnPRansac: more than %d correspondences", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
+    HIP_TRY(hipMemcpyAsync(ctx->p_obj, obj, (size_t)m * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->p_img, img, (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->m_n, &m, 4, hipMemcpyHostToDevice, ctx->stream));
+    // the single-call path has no MIN_MATCHES gate (that gate belongs to the matcher, M:330)
+    int rc;
+    if ((rc = pnp_run_candidates(ctx, 1, nullptr, K4, iters, thr_px, conf, seed, RELOC_PNP_SAMPLE))) return rc;
+    PnpOut po;
+    HIP_TRY(hipMemcpyAsync(&po, ctx->p_out, sizeof(po), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (po.ok) {
+        HIP_TRY(hipMemcpyAsync(inliers, ctx->p_inl, (size_t)po.n_inl * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 3; ++k) { rvec[k] = po.rvec[k]; tvec[k] = po.Rt[9 + k]; }
+        *n_inl = po.n_inl;
+        *ok = 1;
+    }
+    return RELOC_OK;
+}

@@ -1,0 +1,396 @@
+// reloc_tick.hip -- the fused repeat tick on gfx950: every step between "frame in HBM" and
+// "anchor pose" runs on the device, the host only enqueues kernels.
+//
+// Mirrors VisualLandmarkMatcher._tick (reference M:281-433) and the whole-database candidate search
+// of the global-relocalisation variant (reference G:315-344, gates G:381-382, no consistency gate
+// G:424):
+//   ORB (reloc_orb.hip) -> candidates (local: nearest 15 by VIO distance, radius 8 m, heading 90 deg,
+//   first 5;  global: mutual-match count of every heading-compatible record, top 25) ->
+//   mutual matches of each candidate (reloc_match.hip, emit mode) -> gather 3-D/2-D pairs ->
+//   PnP-RANSAC batch (reloc_pnp.hip) -> gates, pose composition, best by inliers, consistency.
+#include "reloc_internal.h"
+
+struct TickParams {
+    double base_pose[7];
+    double b2c_t[3];
+    double b2c_R[9];
+    int global_reloc;
+    int check_consistency;
+    int n_records;
+};
+
+__device__ void quat_to_rot(double qx, double qy, double qz, double qw, double R[9])
+{
+    R[0] = 1 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qz * qw);     R[2] = 2 * (qx * qz + qy * qw);
+    R[3] = 2 * (qx * qy + qz * qw);     R[4] = 1 - 2 * (qx * qx + qz * qz); R[5] = 2 * (qy * qz - qx * qw);
+    R[6] = 2 * (qx * qz - qy * qw);     R[7] = 2 * (qy * qz + qx * qw);     R[8] = 1 - 2 * (qx * qx + qy * qy);
+}
+
+__device__ void rot_to_quat(const double R[9], double q[4])
+{
+    const double tr = R[0] + R[4] + R[8];
+    double qx, qy, qz, qw;
+    if (tr > 0) {
+        const double s = 0.5 / sqrt(tr + 1.0);
+        qw = 0.25 / s;
+        qx = (R[7] - R[5]) * s; qy = (R[2] - R[6]) * s; qz = (R[3] - R[1]) * s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        const double s = 2.0 * sqrt(1.0 + R[0] - R[4] - R[8]);
+        qw = (R[7] - R[5]) / s; qx = 0.25 * s; qy = (R[1] + R[3]) / s; qz = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        const double s = 2.0 * sqrt(1.0 + R[4] - R[0] - R[8]);
+        qw = (R[2] - R[6]) / s; qx = (R[1] + R[3]) / s; qy = 0.25 * s; qz = (R[5] + R[7]) / s;
+    } else {
+        const double s = 2.0 * sqrt(1.0 + R[8] - R[0] - R[4]);
+        qw = (R[3] - R[1]) / s; qx = (R[2] + R[6]) / s; qy = (R[5] + R[7]) / s; qz = 0.25 * s;
+    }
+    q[0] = qx; q[1] = qy; q[2] = qz; q[3] = qw;
+}
+
+__device__ __forceinline__ double hdg_err_of(double teach_hdg, double cur_hdg)
+{
+    const double d = teach_hdg - cur_hdg;
+    return fabs(atan2(sin(d), cos(d)));
+}
+
+// ---- candidate selection, local mode (M:293-302) --------------------------------------------------
+// One workgroup.  15 rounds of "smallest (distance, index) not yet taken", then the radius/heading
+// filter in that order, first 5 kept.
+__global__ __launch_bounds__(1024) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
+                                                           int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
+{
+    __shared__ double s_d[1024];
+    __shared__ int s_i[1024];
+    __shared__ int s_pick[RELOC_MAX_CANDIDATES * 3];
+    __shared__ double s_pickd[RELOC_MAX_CANDIDATES * 3];
+    const int tid = threadIdx.x;
+    const int L = prm.n_records;
+    const double vx = prm.base_pose[0], vy = prm.base_pose[1];
+    const int rounds = min(RELOC_MAX_CANDIDATES * 3, L);
+    double last_d = -1.0;
+    int last_i = -1;
+    for (int r = 0; r < rounds; ++r) {
+        double bd = 1e300;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < L; i += 1024) {
+            const double dx = xyh[3 * i] - vx, dy = xyh[3 * i + 1] - vy;
+            const double d = sqrt(dx * dx + dy * dy);
+            // strictly after the previous pick in (d, i) order
+            const bool after = d > last_d || (d == last_d && i > last_i);
+            if (after && (d < bd || (d == bd && i < bi))) { bd = d; bi = i; }
+        }
+        s_d[tid] = bd; s_i[tid] = bi;
+        __syncthreads();
+        for (int s = 512; s >= 1; s >>= 1) {
+            if (tid < s) {
+                const double od = s_d[tid + s]; const int oi = s_i[tid + s];
+                if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        last_d = s_d[0]; last_i = s_i[0];
+        if (tid == 0) { s_pick[r] = last_i; s_pickd[r] = last_d; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double Rb[9];
+        quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
+        const double cur_hdg = atan2(Rb[3], Rb[0]);
+        const double tol = RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0;
+        int n = 0;
+        for (int r = 0; r < rounds && n < RELOC_MAX_CANDIDATES; ++r) {
+            const int i = s_pick[r];
+            if (i == 0x7fffffff) break;
+            if (s_pickd[r] < RELOC_CANDIDATE_RADIUS_M && hdg_err_of(xyh[3 * i + 2], cur_hdg) < tol) cand_ids[n++] = i;
+        }
+        *cand_n = n;
+    }
+}
+
+// ---- candidate selection, global mode (G:329-344) -------------------------------------------------
+// top-k of (count, id) descending among heading-compatible records with count >= MIN_MATCHES.
+// xyh == NULL skips the heading mask (plain top-k of the counts: sharded scan).
+__global__ __launch_bounds__(1024) void k_topk_counts(const int32_t *__restrict__ counts, const double *__restrict__ xyh,
+                                                      TickParams prm, int k, int id_base, int32_t *__restrict__ out_ids,
+                                                      int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n)
+{
+    __shared__ unsigned long long s_key[1024];
+    const int tid = threadIdx.x;
+    const int L = prm.n_records;
+    double cur_hdg = 0;
+    const double tol = RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0;
+    if (xyh) {
+        double Rb[9];
+        quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
+        cur_hdg = atan2(Rb[3], Rb[0]);
+    }
+    unsigned long long last = ~0ull;
+    int n = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = 0;
+        for (int i = tid; i < L; i += 1024) {
+            const int c = counts[i];
+            if (c < RELOC_MIN_MATCHES) continue;
+            if (xyh && !(hdg_err_of(xyh[3 * i + 2], cur_hdg) < tol)) continue;
+            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
+            if (key < last && key > best) best = key;
+        }
+        s_key[tid] = best;
+        __syncthreads();
+        for (int s = 512; s >= 1; s >>= 1) {
+            if (tid < s && s_key[tid + s] > s_key[tid]) s_key[tid] = s_key[tid + s];
+            __syncthreads();
+        }
+        const unsigned long long top = s_key[0];
+        __syncthreads();
+        if (top == 0) break;
+        if (tid == 0) {
+            out_ids[n] = (int32_t)((unsigned)(top & 0xFFFFFFFFu) - 1) + id_base;
+            if (out_counts) out_counts[n] = (int32_t)(top >> 32);
+        }
+        ++n;
+        last = top;
+    }
+    if (tid == 0) {
+        *out_n = n;
+        for (int r = n; r < k; ++r) { out_ids[r] = -1; if (out_counts) out_counts[r] = 0; }
+    }
+}
+
+// ---- gather (M:333-336) ---------------------------------------------------------------------------
+// grid MAX_CAND, block 256: obj = keypoints_3d_cam[queryIdx], img = pts_curr_2d[trainIdx]
+__global__ __launch_bounds__(256) void k_gather(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
+                                                const int64_t *__restrict__ off, const float *__restrict__ pts3d,
+                                                const float *__restrict__ f_xy, const int32_t *__restrict__ m_qidx,
+                                                const int32_t *__restrict__ m_tidx, const int32_t *__restrict__ m_n,
+                                                float *__restrict__ p_obj, float *__restrict__ p_img)
+{
+    const int s = blockIdx.x;
+    if (s >= *cand_n) return;
+    const int r = cand_ids[s];
+    const int64_t row0 = off[r];
+    const int m = m_n[s];
+    for (int k = threadIdx.x; k < m; k += 256) {
+        const int64_t q = row0 + m_qidx[(size_t)s * MAX_REC_ROWS + k];
+        const int t = m_tidx[(size_t)s * MAX_REC_ROWS + k];
+        float *o = p_obj + ((size_t)s * MAX_REC_ROWS + k) * 3;
+        o[0] = pts3d[3 * q]; o[1] = pts3d[3 * q + 1]; o[2] = pts3d[3 * q + 2];
+        float *im = p_img + ((size_t)s * MAX_REC_ROWS + k) * 2;
+        im[0] = f_xy[2 * t]; im[1] = f_xy[2 * t + 1];
+    }
+}
+
+// ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
+__global__ void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
+                                const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
+                                const int32_t *__restrict__ f_count, TickParams prm, TickResult *__restrict__ res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    TickResult out;
+    for (int k = 0; k < 7; ++k) out.anchor_pose[k] = 0;
+    out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.pad = 0;
+    out.n_features = *f_count;
+    const int nc = *cand_n;
+    out.n_candidates = nc;
+    if (out.n_features < RELOC_MIN_MATCHES) { out.outcome = RELOC_OUT_NO_FEATURES; *res = out; return; }
+    if (nc == 0) { out.outcome = RELOC_OUT_NO_CANDIDATES; *res = out; return; }
+    const int min_inl = prm.global_reloc ? 18 : RELOC_MIN_INLIERS;            // G:85
+    const double max_err = prm.global_reloc ? 1.5 : RELOC_REPROJ_MAX_PX;      // G:86
+    int best = -1, best_inl = 0;
+    double best_pose[7], best_err = 0;
+    for (int s = 0; s < nc; ++s) {
+        const PnpOut &p = pnp[s];
+        if (!p.ok || p.n_inl < min_inl) continue;
+        if (p.reproj_mean > max_err) continue;
+        const double *R = p.Rt, *t = p.Rt + 9;
+        // invert: current camera in the teach camera frame
+        double Rtc[9], ttc[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Rtc[3 * r + c] = R[3 * c + r];
+        for (int r = 0; r < 3; ++r) ttc[r] = -(Rtc[3 * r] * t[0] + Rtc[3 * r + 1] * t[1] + Rtc[3 * r + 2] * t[2]);
+        const double *tp = db_pose + 7 * (size_t)cand_ids[s];
+        double Rwt[9];
+        quat_to_rot(tp[3], tp[4], tp[5], tp[6], Rwt);
+        double Rwc[9], twc[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c)
+                Rwc[3 * r + c] = Rwt[3 * r] * Rtc[c] + Rwt[3 * r + 1] * Rtc[3 + c] + Rwt[3 * r + 2] * Rtc[6 + c];
+            twc[r] = tp[r] + (Rwt[3 * r] * ttc[0] + Rwt[3 * r + 1] * ttc[1] + Rwt[3 * r + 2] * ttc[2]);
+        }
+        double q[4];
+        rot_to_quat(Rwc, q);
+        // camera world pose -> base_link world pose (M:160-172), through the quaternion as the reference does
+        double Rq[9];
+        quat_to_rot(q[0], q[1], q[2], q[3], Rq);
+        double Rwb[9], twb[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rwb[3 * r + c] = Rq[3 * r] * prm.b2c_R[3 * c] + Rq[3 * r + 1] * prm.b2c_R[3 * c + 1] + Rq[3 * r + 2] * prm.b2c_R[3 * c + 2];
+        for (int r = 0; r < 3; ++r)
+            twb[r] = twc[r] - (Rwb[3 * r] * prm.b2c_t[0] + Rwb[3 * r + 1] * prm.b2c_t[1] + Rwb[3 * r + 2] * prm.b2c_t[2]);
+        double qb[4];
+        rot_to_quat(Rwb, qb);
+        if (best < 0 || p.n_inl > best_inl) {
+            best = s; best_inl = p.n_inl; best_err = p.reproj_mean;
+            best_pose[0] = twb[0]; best_pose[1] = twb[1]; best_pose[2] = twb[2];
+            best_pose[3] = qb[0]; best_pose[4] = qb[1]; best_pose[5] = qb[2]; best_pose[6] = qb[3];
+        }
+    }
+    if (best < 0) { out.outcome = RELOC_OUT_NO_PNP_ACCEPT; *res = out; return; }
+    for (int k = 0; k < 7; ++k) out.anchor_pose[k] = best_pose[k];
+    out.n_inl = best_inl;
+    out.reproj = best_err;
+    out.lm_idx = cand_ids[best];
+    const double dx = best_pose[0] - prm.base_pose[0], dy = best_pose[1] - prm.base_pose[1];
+    const double shift = sqrt(dx * dx + dy * dy);
+    out.outcome = (prm.check_consistency && shift > RELOC_CONSISTENCY_M) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
+    *res = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+static TickParams make_tick_params(reloc_ctx *ctx, const double base_pose[7], int global_reloc, int check_consistency)
+{
+    TickParams p;
+    for (int k = 0; k < 7; ++k) p.base_pose[k] = base_pose[k];
+    for (int k = 0; k < 3; ++k) p.b2c_t[k] = ctx->b2c_t[k];
+    for (int k = 0; k < 9; ++k) p.b2c_R[k] = ctx->b2c_R[k];
+    p.global_reloc = global_reloc;
+    p.check_consistency = check_consistency;
+    p.n_records = (int)ctx->db_records;
+    return p;
+}
+
+static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
+{
+    int rc;
+    hipStream_t st = ctx->stream;
+    // mutual matches of every candidate, in queryIdx order
+    if ((rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
+                             ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
+                             ctx->m_dist, ctx->m_n, MAX_REC_ROWS)))
+        return rc;
+    hipLaunchKernelGGL(k_gather, dim3(MAX_CAND), dim3(256), 0, st, ctx->cand_ids, ctx->cand_n, ctx->db_off, ctx->db_pts3d,
+                       ctx->f_xy, ctx->m_qidx, ctx->m_tidx, ctx->m_n, ctx->p_obj, ctx->p_img);
+    if ((rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, RELOC_RANSAC_ITERATIONS, (float)RELOC_RANSAC_REPROJ_PX,
+                                 RELOC_RANSAC_CONFIDENCE, seed, RELOC_MIN_MATCHES)))
+        return rc;
+    hipLaunchKernelGGL(k_tick_finalize, dim3(1), dim3(64), 0, st, ctx->cand_ids, ctx->cand_n, ctx->p_out, ctx->db_pose,
+                       ctx->f_count, prm, ctx->tick_res);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double base_to_cam_t[3], const double base_to_cam_R[9])
+{
+    ARG_CHECK(ctx, "ctx is NULL");
+    if (K4) for (int k = 0; k < 4; ++k) ctx->K4[k] = K4[k];
+    if (base_to_cam_t) for (int k = 0; k < 3; ++k) ctx->b2c_t[k] = base_to_cam_t[k];
+    if (base_to_cam_R) for (int k = 0; k < 9; ++k) ctx->b2c_R[k] = base_to_cam_R[k];
+    return db_reindex(ctx);
+}
+
+RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
+                             int global_reloc, uint64_t seed)
+{
+    ARG_CHECK(ctx && img_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_dev");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (ctx->max_feat > 65535) { reloc_set_error("tick: max_feat must be <= 65535"); return RELOC_E_CAPACITY; }
+    int rc;
+    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
+    const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, !global_reloc);
+    hipStream_t st = ctx->stream;
+    if (global_reloc) {
+        if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) return rc;
+        hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, st, ctx->db_counts, ctx->db_xy_heading, prm,
+                           RELOC_GLOBAL_MAX_CANDIDATES, 0, ctx->cand_ids, (int32_t *)nullptr, ctx->cand_n);
+    } else {
+        hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(1024), 0, st, ctx->db_xy_heading, prm, ctx->cand_ids, ctx->cand_n);
+    }
+    return tick_solve(ctx, prm, seed);
+}
+
+RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj, int32_t *lm_idx,
+                                int32_t *outcome, int32_t *n_candidates)
+{
+    ARG_CHECK(ctx, "ctx is NULL");
+    TickResult r;
+    HIP_TRY(hipMemcpyAsync(&r, ctx->tick_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
+    if (n_inl) *n_inl = r.n_inl;
+    if (reproj) *reproj = (float)r.reproj;
+    if (lm_idx) *lm_idx = r.lm_idx;
+    if (outcome) *outcome = r.outcome;
+    if (n_candidates) *n_candidates = r.n_candidates;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int order, const double base_pose[7],
+                         int global_reloc, uint64_t seed, double anchor_pose[7], int32_t *n_inl, float *reproj,
+                         int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates)
+{
+    ARG_CHECK(ctx && img && base_pose && w >= 64 && h >= 64, "reloc_tick");
+    if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
+    HIP_TRY(hipMemcpyAsync(ctx->frame_img, img, (size_t)w * h * 3, hipMemcpyHostToDevice, ctx->stream));
+    int rc = reloc_tick_dev(ctx, ctx->frame_img, w, h, order, base_pose, global_reloc, seed);
+    if (rc) return rc;
+    return reloc_tick_result(ctx, anchor_pose, n_inl, reproj, lm_idx, outcome, n_candidates);
+}
+
+// ---- sharded database: scan and solve halves ------------------------------------------------------
+RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, int32_t *topk_ids_dev,
+                                  int32_t *topk_counts_dev, int k)
+{
+    ARG_CHECK(ctx && img_dev && topk_ids_dev && topk_counts_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64,
+              "reloc_tick_scan_dev");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    int rc;
+    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
+    if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) return rc;
+    double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
+    const TickParams prm = make_tick_params(ctx, zero_pose, 1, 0);
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_counts, (const double *)nullptr, prm, k, 0,
+                       topk_ids_dev, topk_counts_dev, ctx->cand_n);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+__global__ void k_set_candidates(const int32_t *__restrict__ ids, int n, int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
+{
+    if (threadIdx.x == 0) {
+        int m = 0;
+        for (int i = 0; i < n; ++i)
+            if (ids[i] >= 0) cand_ids[m++] = ids[i];
+        *cand_n = m;
+    }
+}
+
+RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand, const double base_pose[7],
+                                   int check_consistency, uint64_t seed)
+{
+    ARG_CHECK(ctx && cand_ids_dev && base_pose && n_cand >= 0 && n_cand <= MAX_CAND, "reloc_tick_solve_dev");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    hipLaunchKernelGGL(k_set_candidates, dim3(1), dim3(64), 0, ctx->stream, cand_ids_dev, n_cand, ctx->cand_ids, ctx->cand_n);
+    const TickParams prm = make_tick_params(ctx, base_pose, !check_consistency, check_consistency);
+    return tick_solve(ctx, prm, seed);
+}
+
+// read back the per-candidate PnP records of the last tick (parity taps for tests)
+RELOC_API int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches, int32_t *n_inl,
+                               int32_t *ok, double *reproj, double *Rt)
+{
+    ARG_CHECK(ctx && cand_ids && n_cand, "reloc_tick_debug");
+    PnpOut po[MAX_CAND];
+    HIP_TRY(hipMemcpyAsync(n_cand, ctx->cand_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(cand_ids, ctx->cand_ids, sizeof(int32_t) * MAX_CAND, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(po, ctx->p_out, sizeof(po), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < *n_cand && s < MAX_CAND; ++s) {
+        if (n_matches) n_matches[s] = po[s].n_matches;
+        if (n_inl) n_inl[s] = po[s].n_inl;
+        if (ok) ok[s] = po[s].ok;
+        if (reproj) reproj[s] = po[s].reproj_mean;
+        if (Rt) memcpy(Rt + 12 * s, po[s].Rt, sizeof(double) * 12);
+    }
+    return RELOC_OK;
+}

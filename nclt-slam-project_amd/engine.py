@@ -213,6 +213,21 @@ class Engine:
         return bool(ok.value), rvec, tvec, inl[: n.value].copy()
 
     # ------------------------------------------------------------------ fused tick
+    def set_camera(self, K4=None, base_to_cam_t=None, base_to_cam_R=None):
+        a = None if K4 is None else np.ascontiguousarray(K4, np.float64).reshape(4)
+        b = None if base_to_cam_t is None else np.ascontiguousarray(base_to_cam_t, np.float64).reshape(3)
+        c = None if base_to_cam_R is None else np.ascontiguousarray(base_to_cam_R, np.float64).reshape(9)
+        N.check(self._lib.reloc_set_camera(self._ctx, N.ptr(a), N.ptr(b), N.ptr(c)), "reloc_set_camera")
+
+    def tick_debug(self):
+        ids = np.zeros(32, np.int32); n = C.c_int32(); nm = np.zeros(32, np.int32); ni = np.zeros(32, np.int32)
+        ok = np.zeros(32, np.int32); rep = np.zeros(32); Rt = np.zeros((32, 12))
+        N.check(self._lib.reloc_tick_debug(self._ctx, N.ptr(ids), C.byref(n), N.ptr(nm), N.ptr(ni), N.ptr(ok), N.ptr(rep),
+                                           N.ptr(Rt)), "reloc_tick_debug")
+        k = n.value
+        return dict(cand_ids=ids[:k].copy(), n_matches=nm[:k].copy(), n_inliers=ni[:k].copy(), ok=ok[:k].copy(),
+                    reproj=rep[:k].copy(), Rt=Rt[:k].copy())
+
     def tick(self, img, base_pose, order_rgb=False, global_reloc=False, seed=0):
         img = N.u8(img)
         h, w, _ = img.shape
