@@ -122,3 +122,61 @@ def descriptor_db(rng, n_records, rows="fixed64", cur=None, planted_records=(), 
             src = rng.choice(len(cur), k, replace=False)
             desc[off[r]:off[r] + k] = perturb_descriptors(rng, cur[src], flip_p)
     return desc, pts3d, off, poses
+
+
+# ---------------------------------------------------------------------------------------------------
+# A renderable scene: one large textured wall in front of the robot, seen by a pinhole camera mounted
+# on base_link (0.35 m forward, 0.18 m up, optical frame right-down-forward).
+class WallScene:
+    """world: x forward, y left, z up.  The wall is the plane x = wall_x; its texture is metric
+    (`m_per_px` metres per texel).  render(base_pose) -> (bgr (H,W,3) u8, depth_mm (H,W) u16)."""
+
+    # optical axes expressed in base_link coordinates (columns): x_cam = -y, y_cam = -z, z_cam = +x
+    R_BASE_CAM = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    T_BASE_CAM = np.array([0.35, 0.0, 0.18])
+
+    def __init__(self, seed=20260501, wall_x=16.0, m_per_px=0.02, tex_w=2400, tex_h=1200, w=640, h=480, noise=2.0):
+        rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.tex = textured_frame(rng, tex_w, tex_h, n_shapes=2600, noise=0.0).astype(np.float32)
+        self.wall_x, self.m_per_px, self.w, self.h, self.noise = wall_x, m_per_px, w, h, noise
+        v, u = np.mgrid[0:h, 0:w]
+        self.rays = np.stack([(u - CX) / FX, (v - CY) / FY, np.ones_like(u, dtype=np.float64)], axis=-1)  # camera frame
+
+    @staticmethod
+    def _quat_to_rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def render(self, base_pose):
+        R_wb = self._quat_to_rot(base_pose[3:7])
+        c = np.asarray(base_pose[:3], np.float64) + R_wb @ self.T_BASE_CAM
+        R_wc = R_wb @ self.R_BASE_CAM
+        d = self.rays @ R_wc.T                                  # ray directions in the world
+        lam = (self.wall_x - c[0]) / np.where(np.abs(d[..., 0]) < 1e-9, 1e-9, d[..., 0])
+        hit = lam > 0
+        py = c[1] + lam * d[..., 1]
+        pz = c[2] + lam * d[..., 2]
+        th, tw = self.tex.shape[:2]
+        tu = (tw / 2.0) - py / self.m_per_px                    # +y (left) -> smaller texture u
+        tv = (th / 2.0) - (pz - 1.0) / self.m_per_px            # wall centred 1 m above ground
+        inside = hit & (tu >= 0) & (tu < tw - 1) & (tv >= 0) & (tv < th - 1)
+        tu = np.clip(tu, 0, tw - 1.001); tv = np.clip(tv, 0, th - 1.001)
+        u0 = tu.astype(np.int64); v0 = tv.astype(np.int64)
+        a = (tu - u0)[..., None]; b = (tv - v0)[..., None]
+        t = self.tex
+        img = (t[v0, u0] * (1 - a) * (1 - b) + t[v0, u0 + 1] * a * (1 - b) + t[v0 + 1, u0] * (1 - a) * b + t[v0 + 1, u0 + 1] * a * b)
+        img = np.where(inside[..., None], img, 90.0)
+        if self.noise > 0:   # noise is a function of the pose, so a render does not depend on call order
+            import zlib
+            key = zlib.crc32(np.asarray(base_pose, np.float64).tobytes())
+            img = img + np.random.default_rng([self.seed, key]).normal(0, self.noise, img.shape)
+        depth = np.where(inside, lam, 0.0) * 1000.0             # z along the optical axis = lam (rays have z = 1)
+        return (np.clip(np.rint(img), 0, 255).astype(np.uint8), np.clip(np.rint(depth), 0, 65535).astype(np.uint16))
+
+
+def base_pose(x, y, yaw_deg=0.0, z=0.0):
+    q = quat_from_yaw_pitch_roll(np.deg2rad(yaw_deg))
+    return (float(x), float(y), float(z), float(q[0]), float(q[1]), float(q[2]), float(q[3]))
