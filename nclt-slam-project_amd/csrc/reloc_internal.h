@@ -120,7 +120,7 @@ struct reloc_ctx {
     float *db_pts3d = nullptr;
     int64_t *db_off = nullptr;
     double *db_pose = nullptr;
-    double *db_xy_heading = nullptr; // L x 3 (x, y, heading) for candidate selection
+    double *db_xy_heading = nullptr; // L x 4 (x, y, cos heading, sin heading) for candidate selection
     int32_t *db_counts = nullptr;    // L per-record mutual counts
 
     // ---- tick state ----

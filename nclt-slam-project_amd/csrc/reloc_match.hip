@@ -530,9 +530,11 @@ __global__ void k_db_index(const double *__restrict__ pose, int64_t n, double b0
     const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
     const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
     const double fx = r00 * b0 + r01 * b1 + r02 * b2, fy = r10 * b0 + r11 * b1 + r12 * b2;
-    xyh[3 * i] = pose[7 * i];
-    xyh[3 * i + 1] = pose[7 * i + 1];
-    xyh[3 * i + 2] = atan2(fy, fx);
+    const double fn = sqrt(fx * fx + fy * fy);
+    xyh[4 * i] = pose[7 * i];
+    xyh[4 * i + 1] = pose[7 * i + 1];
+    xyh[4 * i + 2] = fn > 0 ? fx / fn : 1.0;      // cos(heading)
+    xyh[4 * i + 3] = fn > 0 ? fy / fn : 0.0;      // sin(heading)
 }
 
 int db_reindex(reloc_ctx *ctx)
@@ -567,7 +569,7 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     HIP_TRY(hipMalloc((void **)&ctx->db_pts3d, (size_t)(T > 0 ? T : 1) * 12));
     HIP_TRY(hipMalloc((void **)&ctx->db_off, (size_t)(n_records + 1) * 8));
     HIP_TRY(hipMalloc((void **)&ctx->db_pose, (size_t)(n_records > 0 ? n_records : 1) * 56));
-    HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 24));
+    HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 32));
     HIP_TRY(hipMalloc((void **)&ctx->db_counts, (size_t)(n_records > 0 ? n_records : 1) * 4));
     if (T > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_desc, desc, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));

@@ -62,29 +62,39 @@ __device__ __forceinline__ int reflect101(int p, int n)
 }
 
 // ---- gray ---------------------------------------------------------------------------------------
-// 4 pixels per lane: 12 source bytes -> one dword of level 0.  Block 0 also clears the per-frame
-// counters (histograms, candidate counts).
+// 4 pixels per lane: 12 source bytes (three aligned dwords when the frame allows it) -> one dword of
+// level 0.  Block 0 also clears the per-frame counters (histograms, candidate counts).
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_gray_l0(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
                                                  uint8_t *__restrict__ dst, int dstride, int32_t *__restrict__ hist,
                                                  int32_t *__restrict__ cand_cnt)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < NLEV * 256; i += 256) hist[i] = 0;
         if (threadIdx.x < NLEV) cand_cnt[threadIdx.x] = 0;
     }
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (x4 >= w) return;
+    const int qpr = (w + 3) >> 2;                       // quads per row
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * h) return;
+    const int y = q / qpr, x4 = (q - y * qpr) * 4;
     const uint8_t *s = src + (size_t)y * sstride + 3 * x4;
+    uint8_t px[12];
+    if (ALIGNED) {
+        const u32 *s4 = reinterpret_cast<const u32 *>(s);
+        const u32 d0 = s4[0], d1 = s4[1], d2 = s4[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { px[k] = (d0 >> (8 * k)) & 0xFF; px[4 + k] = (d1 >> (8 * k)) & 0xFF; px[8 + k] = (d2 >> (8 * k)) & 0xFF; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) px[k] = (x4 + k / 3 < w) ? s[k] : 0;
+    }
     u32 out = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (x4 + k < w) {
-            const int c0 = s[3 * k], c1 = s[3 * k + 1], c2 = s[3 * k + 2];
-            const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
-            const int g = (b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
-            out |= (u32)g << (8 * k);
-        }
+        const int c0 = px[3 * k], c1 = px[3 * k + 1], c2 = px[3 * k + 2];
+        const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
+        const int g = (b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
+        if (x4 + k < w) out |= (u32)g << (8 * k);
     }
     *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;
 }
@@ -108,29 +118,50 @@ __global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ 
 }
 
 // ---- pyramid ------------------------------------------------------------------------------------
+// 4 output pixels per lane.  With a 1.2 scale step their taps span at most 7 source bytes per row, so
+// each source row is fetched as three aligned dwords instead of eight byte loads.  (Rows are padded to
+// a 64-byte stride inside an arena with slack, so the 12-byte window never leaves the allocation.)
+__device__ __forceinline__ u32 byte_at(u32 d0, u32 d1, u32 d2, int k)
+{
+    const unsigned long long lo = ((unsigned long long)d1 << 32) | d0, hi = ((unsigned long long)d2 << 32) | d1;
+    return (u32)((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4))) & 0xFF);
+}
+
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
                                                 uint8_t *__restrict__ dst, int dw, int dh, int dstride,
                                                 const int32_t *__restrict__ xofs, const int32_t *__restrict__ xcoef,
                                                 const int32_t *__restrict__ yofs, const int32_t *__restrict__ ycoef)
 {
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (x4 >= dstride) return;
-    const int y0 = yofs[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
-    const u32 b = (u32)ycoef[y];
-    const uint8_t *r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
-    const u32 one = 1u << RELOC_RESIZE_COEF_BITS;
+    const int qpr = dstride >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= qpr * dh) return;
+    const int y = q / qpr, x4 = (q - y * qpr) * 4;
     u32 out = 0;
+    if (x4 < dw) {
+        const int y0 = yofs[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+        const u32 b = (u32)ycoef[y];
+        const u32 one = 1u << RELOC_RESIZE_COEF_BITS;
+        int xo[4];
+        u32 xa[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x4 + k;
-        if (x < dw) {
-            const int x0 = xofs[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;
-            const u32 a = (u32)xcoef[x];
-            const u32 h0 = r0[x0] * (one - a) + r0[x1] * a;
-            const u32 h1 = r1[x0] * (one - a) + r1[x1] * a;
-            const u32 v = h0 * (one - b) + h1 * b;
-            out |= ((v + (1u << 15)) >> 16) << (8 * k);
+        for (int k = 0; k < 4; ++k) {
+            const int x = x4 + k < dw ? x4 + k : dw - 1;
+            xo[k] = xofs[x];
+            xa[k] = (u32)xcoef[x];
+        }
+        const int base = xo[0] & ~3;
+        const u32 *r0 = reinterpret_cast<const u32 *>(src + (size_t)y0 * sstride + base);
+        const u32 *r1 = reinterpret_cast<const u32 *>(src + (size_t)y1 * sstride + base);
+        const u32 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (x4 + k < dw) {
+                const int k0 = xo[k] - base, k1 = (xo[k] + 1 < sw ? xo[k] + 1 : sw - 1) - base;
+                const u32 h0 = byte_at(a0, a1, a2, k0) * (one - xa[k]) + byte_at(a0, a1, a2, k1) * xa[k];
+                const u32 h1 = byte_at(b0, b1, b2, k0) * (one - xa[k]) + byte_at(b0, b1, b2, k1) * xa[k];
+                const u32 v = h0 * (one - b) + h1 * b;
+                out |= ((v + (1u << 15)) >> 16) << (8 * k);
+            }
         }
     }
     *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;   // padding columns are written as 0
@@ -342,6 +373,34 @@ __device__ int stage1_cut(const int32_t *__restrict__ hist_l, int n_keep, int *s
     return *s_cut;
 }
 
+// Harris response of one pixel by a whole wave: lanes 0..48 own one pixel of the 7x7 block each.
+__device__ float harris_wave(const uint8_t *p, int step, int lane)
+{
+    int a = 0, b = 0, c = 0;
+    if (lane < 49) {
+        const int dy = lane / 7 - 3, dx = lane % 7 - 3;
+        const uint8_t *q = p + dy * step + dx;
+        const int ix = (q[1] - q[-1]) * 2 + (q[-step + 1] - q[-step - 1]) + (q[step + 1] - q[step - 1]);
+        const int iy = (q[step] - q[-step]) * 2 + (q[step - 1] - q[-step - 1]) + (q[step + 1] - q[-step + 1]);
+        a = ix * ix; b = iy * iy; c = ix * iy;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        a += __shfl_xor(a, k);
+        b += __shfl_xor(b, k);
+        c += __shfl_xor(c, k);
+    }
+    const float scale = __fdiv_rn(1.f, (float)((1 << 2) * RELOC_HARRIS_BLOCK) * 255.f);
+    const float s2 = __fmul_rn(scale, scale), s3 = __fmul_rn(s2, scale), s4 = __fmul_rn(s3, scale);
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float t1 = __fmul_rn(fa, fb), t2 = __fmul_rn(fc, fc), t3 = __fadd_rn(fa, fb);
+    const float t4 = __fmul_rn(RELOC_HARRIS_K, t3), t5 = __fmul_rn(t4, t3);
+    const float t6 = __fsub_rn(t1, t2), t7 = __fsub_rn(t6, t5);
+    return __fmul_rn(t7, s4);
+}
+
+// Each block scans 4096 bytes of the NMS map, collects the survivors >= cut in LDS, then its four waves
+// compute their Harris responses (one wave per survivor) and append them to the level's candidate list.
 __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
                                                 const uint8_t *__restrict__ nms, const int32_t *__restrict__ hist,
                                                 int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
@@ -349,28 +408,43 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
 {
     __shared__ int s_suf[256];
     __shared__ int s_cut;
+    __shared__ int s_n;
+    __shared__ u32 s_list[4096];
     const int l = find_level(tab->flat_base, blockIdx.x);
     const OrbLevel L = tab->lev[l];
     if (L.quota <= 0 || L.w <= 2 * RELOC_ORB_EDGE || L.h <= 2 * RELOC_ORB_EDGE) return;
-    const int cut = stage1_cut(hist + l * 256, 2 * L.quota, s_suf, &s_cut);
-    if (dbg_cut && blockIdx.x == tab->flat_base[l] && threadIdx.x == 0) dbg_cut[l] = cut;
     const int64_t idx0 = ((int64_t)(blockIdx.x - tab->flat_base[l]) * 256 + threadIdx.x) * 16;
     const int64_t total = (int64_t)L.stride * L.h;
-    if (idx0 >= total) return;
-    const uint4 v = *reinterpret_cast<const uint4 *>(nms + L.off + idx0);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (idx0 < total) v = *reinterpret_cast<const uint4 *>(nms + L.off + idx0);
+    const bool any = (v.x | v.y | v.z | v.w) != 0;
+    if (threadIdx.x == 0) s_n = 0;
+    if (!__syncthreads_or(any)) return;                      // nothing kept in this chunk: skip the cut computation
+    const int cut = stage1_cut(hist + l * 256, 2 * L.quota, s_suf, &s_cut);
+    if (dbg_cut && threadIdx.x == 0) dbg_cut[l] = cut;
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
-    if (!(v.x | v.y | v.z | v.w)) return;
-    const uint8_t *img = pyr + L.off;
+    if (any) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int s = (wv[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        if (s && s >= cut) {
-            const int64_t idx = idx0 + k;
-            const int y = (int)(idx / L.stride), x = (int)(idx % L.stride);
-            const float r = harris_px(img + (size_t)y * L.stride + x, L.stride);
+        for (int k = 0; k < 16; ++k) {
+            const int sc = (wv[k >> 2] >> (8 * (k & 3))) & 0xFF;
+            if (sc && sc >= cut) {
+                const int64_t idx = idx0 + k;
+                const int y = (int)(idx / L.stride), x = (int)(idx % L.stride);
+                s_list[atomicAdd(&s_n, 1)] = ((u32)y << 16) | (u32)x;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *img = pyr + L.off;
+    for (int i = wave; i < n; i += 4) {
+        const u32 key = s_list[i];
+        const float r = harris_wave(img + (size_t)(key >> 16) * L.stride + (key & 0xFFFF), L.stride, lane);
+        if (lane == 0) {
             const int pos = atomicAdd(&cand_cnt[l], 1);
             if (pos < RELOC_ORB_STAGE1_CAP) {
-                cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = ((u32)y << 16) | (u32)x;
+                cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = key;
                 cand_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = r;
             }
         }
@@ -651,15 +725,21 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
     reloc_prof_begin(ctx, RELOC_PROF_ORB);
     const OrbLevel &L0 = tab_h->lev[0];
     if (channels == 3) {
-        hipLaunchKernelGGL(k_gray_l0, dim3((w + 1023) / 1024, h), dim3(256), 0, st, src_dev, w, h, stride, order,
-                           ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
+        const int quads = ((w + 3) / 4) * h;
+        const bool aligned = (w % 4 == 0) && (stride % 4 == 0) && (((uintptr_t)src_dev) % 4 == 0);
+        if (aligned)
+            hipLaunchKernelGGL(k_gray_l0<true>, dim3((quads + 255) / 256), dim3(256), 0, st, src_dev, w, h, stride, order,
+                               ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
+        else
+            hipLaunchKernelGGL(k_gray_l0<false>, dim3((quads + 255) / 256), dim3(256), 0, st, src_dev, w, h, stride, order,
+                               ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
     } else {
         hipLaunchKernelGGL(k_clear_counters, dim3(1), dim3(256), 0, st, ctx->hist, ctx->cand_cnt);
         HIP_TRY(hipMemcpy2DAsync(ctx->pyr + L0.off, L0.stride, src_dev, stride, w, h, hipMemcpyDeviceToDevice, st));
     }
     for (int l = 1; l < NLEV; ++l) {
         const OrbLevel &S = tab_h->lev[l - 1], &D = tab_h->lev[l];
-        hipLaunchKernelGGL(k_resize, dim3((D.stride / 4 + 255) / 256, D.h), dim3(256), 0, st, ctx->pyr + S.off, S.w, S.h,
+        hipLaunchKernelGGL(k_resize, dim3(((D.stride / 4) * D.h + 255) / 256), dim3(256), 0, st, ctx->pyr + S.off, S.w, S.h,
                            S.stride, ctx->pyr + D.off, D.w, D.h, D.stride, ctx->rz_tab + tab_h->rz_off[l][0],
                            ctx->rz_tab + tab_h->rz_off[l][1], ctx->rz_tab + tab_h->rz_off[l][2],
                            ctx->rz_tab + tab_h->rz_off[l][3]);

@@ -425,25 +425,38 @@ __global__ __launch_bounds__(64) void k_pnp_finish(const float *__restrict__ obj
     const float *im = img + (size_t)c * prm.stride * 2;
     int32_t *inl = inl_out + (size_t)c * prm.stride;
     PnpOut &po = out[c];
-    __shared__ int s_best;
-    // adaptive-cap RANSAC decision (sequential by definition; the counts are tiny)
-    if (lane == 0) {
-        int best = -1;
-        if (m >= prm.min_m) {
-            int niters = prm.iters, best_count = RELOC_PNP_SAMPLE - 1;
-            for (int h = 0; h < prm.iters && h < niters; ++h) {
-                const int ch = cnt[(size_t)c * MAX_HYP + h];
-                if (ch > best_count) {
-                    best = h;
-                    best_count = ch;
-                    niters = ransac_update_iters(prm.conf, (double)(m - ch) / (double)m, niters);
-                }
-            }
-        }
-        s_best = best;
+    // adaptive-cap RANSAC decision.  Sequential semantics ("first hypothesis that beats the best so far,
+    // then shrink the cap"), evaluated by the wave: lane l holds the counts of hypotheses l, l+64, ...;
+    // each step finds the earliest improving hypothesis below the current cap with ballots.
+    int cl[MAX_HYP / 64];
+#pragma unroll
+    for (int j = 0; j < MAX_HYP / 64; ++j) {
+        const int h = j * 64 + lane;
+        cl[j] = h < prm.iters ? cnt[(size_t)c * MAX_HYP + h] : -1;
     }
-    __syncthreads();
-    const int best = s_best;
+    int s_best_v = -1;
+    if (m >= prm.min_m) {
+        int niters = prm.iters, best_count = RELOC_PNP_SAMPLE - 1, pos = 0;
+        for (;;) {
+            int found = -1;
+#pragma unroll
+            for (int j = 0; j < MAX_HYP / 64; ++j) {
+                const int h = j * 64 + lane;
+                const unsigned long long bal = __ballot(h >= pos && h < niters && cl[j] > best_count);
+                if (found < 0 && bal) found = j * 64 + __ffsll((long long)bal) - 1;
+            }
+            if (found < 0) break;
+            const int ch = __shfl(cl[0], found & 63) * (found < 64) +
+                           (MAX_HYP > 64 ? __shfl(cl[1 % (MAX_HYP / 64)], found & 63) * (found >= 64 && found < 128) : 0) +
+                           (MAX_HYP > 128 ? __shfl(cl[2 % (MAX_HYP / 64)], found & 63) * (found >= 128 && found < 192) : 0) +
+                           (MAX_HYP > 192 ? __shfl(cl[3 % (MAX_HYP / 64)], found & 63) * (found >= 192) : 0);
+            s_best_v = found;
+            best_count = ch;
+            niters = ransac_update_iters(prm.conf, (double)(m - ch) / (double)m, niters);
+            pos = found + 1;
+        }
+    }
+    const int best = s_best_v;
     if (best < 0) {
         if (lane == 0) { po.ok = 0; po.n_inl = 0; po.best_h = -1; po.n_matches = m; po.reproj_mean = 0; }
         return;

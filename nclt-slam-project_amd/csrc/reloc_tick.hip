@@ -47,63 +47,91 @@ __device__ void rot_to_quat(const double R[9], double q[4])
     q[0] = qx; q[1] = qy; q[2] = qz; q[3] = qw;
 }
 
-__device__ __forceinline__ double hdg_err_of(double teach_hdg, double cur_hdg)
+// |wrap(teach_hdg - cur_hdg)| < tol  <=>  cos(teach_hdg - cur_hdg) > cos(tol); the database index keeps
+// (cos, sin) of every record's heading, so the test is one dot product (M:296-301).
+__device__ __forceinline__ bool heading_ok(const double *__restrict__ rec4, double cc, double sc, double cos_tol)
 {
-    const double d = teach_hdg - cur_hdg;
-    return fabs(atan2(sin(d), cos(d)));
+    return rec4[2] * cc + rec4[3] * sc > cos_tol;
+}
+
+__device__ __forceinline__ void cur_heading(const TickParams &prm, double &cc, double &sc)
+{
+    double Rb[9];
+    quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
+    const double n = sqrt(Rb[0] * Rb[0] + Rb[3] * Rb[3]);       // fwd = (R00, R10); only the direction matters
+    cc = n > 0 ? Rb[0] / n : 1.0;
+    sc = n > 0 ? Rb[3] / n : 0.0;
+}
+
+// Block-wide "k largest keys, descending" (keys unique, 0 = not eligible): every thread owns the
+// records i = tid, tid+1024, ... and keeps the best key it has not yet given up; per round one
+// wave-shuffle + LDS reduction finds the global maximum and only its owner rescans its few records.
+template <typename KeyFn>
+__device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_red, unsigned long long *out_keys)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto next_below = [&](unsigned long long bound) {
+        unsigned long long best = 0;
+        for (int i = tid; i < L; i += 1024) {
+            const unsigned long long key = keyfn(i);
+            if (key < bound && key > best) best = key;
+        }
+        return best;
+    };
+    unsigned long long mine = next_below(~0ull);
+    int n = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long v = mine;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(v, d);
+            v = o > v ? o : v;
+        }
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        unsigned long long top = s_red[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) top = s_red[w] > top ? s_red[w] : top;
+        __syncthreads();
+        if (top == 0) break;
+        if (tid == 0) out_keys[n] = top;
+        ++n;
+        if (mine == top) mine = next_below(top);
+    }
+    return n;
 }
 
 // ---- candidate selection, local mode (M:293-302) --------------------------------------------------
-// One workgroup.  15 rounds of "smallest (distance, index) not yet taken", then the radius/heading
-// filter in that order, first 5 kept.
+// nearest 15 by (distance, index), then the radius / heading filter in that order, first 5 kept.
+// Order key: the bit pattern of a non-negative double is monotone in its value; the top 44 bits of it
+// order the candidates (ties at that resolution, < 1e-9 relative, fall back to the lower index), the
+// radius test itself uses the exact distance.
 __global__ __launch_bounds__(1024) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
                                                            int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
 {
-    __shared__ double s_d[1024];
-    __shared__ int s_i[1024];
-    __shared__ int s_pick[RELOC_MAX_CANDIDATES * 3];
-    __shared__ double s_pickd[RELOC_MAX_CANDIDATES * 3];
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long s_red[16];
+    __shared__ unsigned long long s_keys[RELOC_MAX_CANDIDATES * 3];
     const int L = prm.n_records;
     const double vx = prm.base_pose[0], vy = prm.base_pose[1];
-    const int rounds = min(RELOC_MAX_CANDIDATES * 3, L);
-    double last_d = -1.0;
-    int last_i = -1;
-    for (int r = 0; r < rounds; ++r) {
-        double bd = 1e300;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < L; i += 1024) {
-            const double dx = xyh[3 * i] - vx, dy = xyh[3 * i + 1] - vy;
-            const double d = sqrt(dx * dx + dy * dy);
-            // strictly after the previous pick in (d, i) order
-            const bool after = d > last_d || (d == last_d && i > last_i);
-            if (after && (d < bd || (d == bd && i < bi))) { bd = d; bi = i; }
+    auto keyfn = [&](int i) -> unsigned long long {
+        const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
+        const double d = sqrt(dx * dx + dy * dy);
+        const unsigned long long q = (unsigned long long)__double_as_longlong(d) >> 20;
+        return ((0xFFFFFFFFFFFull - q) << 20) | (unsigned long long)(0xFFFFF - (i & 0xFFFFF));   // nearer, then lower index
+    };
+    const int n = block_topk(L, min(RELOC_MAX_CANDIDATES * 3, L), keyfn, s_red, s_keys);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double cc, sc;
+        cur_heading(prm, cc, sc);
+        const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
+        int m = 0;
+        for (int r = 0; r < n && m < RELOC_MAX_CANDIDATES; ++r) {
+            const int i = 0xFFFFF - (int)(s_keys[r] & 0xFFFFF);
+            const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
+            if (sqrt(dx * dx + dy * dy) < RELOC_CANDIDATE_RADIUS_M && heading_ok(xyh + 4 * i, cc, sc, cos_tol)) cand_ids[m++] = i;
         }
-        s_d[tid] = bd; s_i[tid] = bi;
-        __syncthreads();
-        for (int s = 512; s >= 1; s >>= 1) {
-            if (tid < s) {
-                const double od = s_d[tid + s]; const int oi = s_i[tid + s];
-                if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
-            }
-            __syncthreads();
-        }
-        last_d = s_d[0]; last_i = s_i[0];
-        if (tid == 0) { s_pick[r] = last_i; s_pickd[r] = last_d; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double Rb[9];
-        quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
-        const double cur_hdg = atan2(Rb[3], Rb[0]);
-        const double tol = RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0;
-        int n = 0;
-        for (int r = 0; r < rounds && n < RELOC_MAX_CANDIDATES; ++r) {
-            const int i = s_pick[r];
-            if (i == 0x7fffffff) break;
-            if (s_pickd[r] < RELOC_CANDIDATE_RADIUS_M && hdg_err_of(xyh[3 * i + 2], cur_hdg) < tol) cand_ids[n++] = i;
-        }
-        *cand_n = n;
+        *cand_n = m;
     }
 }
 
@@ -114,47 +142,31 @@ __global__ __launch_bounds__(1024) void k_topk_counts(const int32_t *__restrict_
                                                       TickParams prm, int k, int id_base, int32_t *__restrict__ out_ids,
                                                       int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n)
 {
-    __shared__ unsigned long long s_key[1024];
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long s_red[16];
+    __shared__ unsigned long long s_keys[MAX_CAND];
     const int L = prm.n_records;
-    double cur_hdg = 0;
-    const double tol = RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0;
-    if (xyh) {
-        double Rb[9];
-        quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
-        cur_hdg = atan2(Rb[3], Rb[0]);
-    }
-    unsigned long long last = ~0ull;
-    int n = 0;
-    for (int r = 0; r < k; ++r) {
-        unsigned long long best = 0;
-        for (int i = tid; i < L; i += 1024) {
-            const int c = counts[i];
-            if (c < RELOC_MIN_MATCHES) continue;
-            if (xyh && !(hdg_err_of(xyh[3 * i + 2], cur_hdg) < tol)) continue;
-            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
-            if (key < last && key > best) best = key;
+    double cc = 1.0, sc = 0.0;
+    if (xyh) cur_heading(prm, cc, sc);
+    const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
+    auto keyfn = [&](int i) -> unsigned long long {
+        const int c = counts[i];
+        if (c < RELOC_MIN_MATCHES) return 0ull;
+        if (xyh && !heading_ok(xyh + 4 * i, cc, sc, cos_tol)) return 0ull;
+        return ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
+    };
+    const int n = block_topk(L, k, keyfn, s_red, s_keys);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < k) {
+        if (tid < n) {
+            out_ids[tid] = (int32_t)((unsigned)(s_keys[tid] & 0xFFFFFFFFu) - 1) + id_base;
+            if (out_counts) out_counts[tid] = (int32_t)(s_keys[tid] >> 32);
+        } else {
+            out_ids[tid] = -1;
+            if (out_counts) out_counts[tid] = 0;
         }
-        s_key[tid] = best;
-        __syncthreads();
-        for (int s = 512; s >= 1; s >>= 1) {
-            if (tid < s && s_key[tid + s] > s_key[tid]) s_key[tid] = s_key[tid + s];
-            __syncthreads();
-        }
-        const unsigned long long top = s_key[0];
-        __syncthreads();
-        if (top == 0) break;
-        if (tid == 0) {
-            out_ids[n] = (int32_t)((unsigned)(top & 0xFFFFFFFFu) - 1) + id_base;
-            if (out_counts) out_counts[n] = (int32_t)(top >> 32);
-        }
-        ++n;
-        last = top;
     }
-    if (tid == 0) {
-        *out_n = n;
-        for (int r = n; r < k; ++r) { out_ids[r] = -1; if (out_counts) out_counts[r] = 0; }
-    }
+    if (tid == 0) *out_n = n;
 }
 
 // ---- gather (M:333-336) ---------------------------------------------------------------------------
@@ -181,70 +193,77 @@ __global__ __launch_bounds__(256) void k_gather(const int32_t *__restrict__ cand
 }
 
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
-__global__ void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
-                                const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
-                                const int32_t *__restrict__ f_count, TickParams prm, TickResult *__restrict__ res)
+// one lane per candidate composes its pose; the best (most inliers, first on ties) is picked by a wave
+// reduction.
+__global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
+                                                      const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
+                                                      const int32_t *__restrict__ f_count, TickParams prm,
+                                                      TickResult *__restrict__ res)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    TickResult out;
-    for (int k = 0; k < 7; ++k) out.anchor_pose[k] = 0;
-    out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.pad = 0;
-    out.n_features = *f_count;
-    const int nc = *cand_n;
-    out.n_candidates = nc;
-    if (out.n_features < RELOC_MIN_MATCHES) { out.outcome = RELOC_OUT_NO_FEATURES; *res = out; return; }
-    if (nc == 0) { out.outcome = RELOC_OUT_NO_CANDIDATES; *res = out; return; }
+    const int s = threadIdx.x;
+    const int nc = min(*cand_n, MAX_CAND);
+    const int nfeat = *f_count;
     const int min_inl = prm.global_reloc ? 18 : RELOC_MIN_INLIERS;            // G:85
     const double max_err = prm.global_reloc ? 1.5 : RELOC_REPROJ_MAX_PX;      // G:86
-    int best = -1, best_inl = 0;
-    double best_pose[7], best_err = 0;
-    for (int s = 0; s < nc; ++s) {
+    bool okc = false;
+    int inl = 0;
+    double err = 0, pose[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (s < nc && nfeat >= RELOC_MIN_MATCHES) {
         const PnpOut &p = pnp[s];
-        if (!p.ok || p.n_inl < min_inl) continue;
-        if (p.reproj_mean > max_err) continue;
-        const double *R = p.Rt, *t = p.Rt + 9;
-        // invert: current camera in the teach camera frame
-        double Rtc[9], ttc[3];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) Rtc[3 * r + c] = R[3 * c + r];
-        for (int r = 0; r < 3; ++r) ttc[r] = -(Rtc[3 * r] * t[0] + Rtc[3 * r + 1] * t[1] + Rtc[3 * r + 2] * t[2]);
-        const double *tp = db_pose + 7 * (size_t)cand_ids[s];
-        double Rwt[9];
-        quat_to_rot(tp[3], tp[4], tp[5], tp[6], Rwt);
-        double Rwc[9], twc[3];
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c)
-                Rwc[3 * r + c] = Rwt[3 * r] * Rtc[c] + Rwt[3 * r + 1] * Rtc[3 + c] + Rwt[3 * r + 2] * Rtc[6 + c];
-            twc[r] = tp[r] + (Rwt[3 * r] * ttc[0] + Rwt[3 * r + 1] * ttc[1] + Rwt[3 * r + 2] * ttc[2]);
-        }
-        double q[4];
-        rot_to_quat(Rwc, q);
-        // camera world pose -> base_link world pose (M:160-172), through the quaternion as the reference does
-        double Rq[9];
-        quat_to_rot(q[0], q[1], q[2], q[3], Rq);
-        double Rwb[9], twb[3];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-                Rwb[3 * r + c] = Rq[3 * r] * prm.b2c_R[3 * c] + Rq[3 * r + 1] * prm.b2c_R[3 * c + 1] + Rq[3 * r + 2] * prm.b2c_R[3 * c + 2];
-        for (int r = 0; r < 3; ++r)
-            twb[r] = twc[r] - (Rwb[3 * r] * prm.b2c_t[0] + Rwb[3 * r + 1] * prm.b2c_t[1] + Rwb[3 * r + 2] * prm.b2c_t[2]);
-        double qb[4];
-        rot_to_quat(Rwb, qb);
-        if (best < 0 || p.n_inl > best_inl) {
-            best = s; best_inl = p.n_inl; best_err = p.reproj_mean;
-            best_pose[0] = twb[0]; best_pose[1] = twb[1]; best_pose[2] = twb[2];
-            best_pose[3] = qb[0]; best_pose[4] = qb[1]; best_pose[5] = qb[2]; best_pose[6] = qb[3];
+        if (p.ok && p.n_inl >= min_inl && !(p.reproj_mean > max_err)) {
+            okc = true;
+            inl = p.n_inl;
+            err = p.reproj_mean;
+            const double *R = p.Rt, *t = p.Rt + 9;
+            double Rtc[9], ttc[3];                       // current camera in the teach camera frame
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Rtc[3 * r + c] = R[3 * c + r];
+            for (int r = 0; r < 3; ++r) ttc[r] = -(Rtc[3 * r] * t[0] + Rtc[3 * r + 1] * t[1] + Rtc[3 * r + 2] * t[2]);
+            const double *tp = db_pose + 7 * (size_t)cand_ids[s];
+            double Rwt[9], Rwc[9], twc[3];
+            quat_to_rot(tp[3], tp[4], tp[5], tp[6], Rwt);
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    Rwc[3 * r + c] = Rwt[3 * r] * Rtc[c] + Rwt[3 * r + 1] * Rtc[3 + c] + Rwt[3 * r + 2] * Rtc[6 + c];
+                twc[r] = tp[r] + (Rwt[3 * r] * ttc[0] + Rwt[3 * r + 1] * ttc[1] + Rwt[3 * r + 2] * ttc[2]);
+            }
+            double q[4], Rq[9], Rwb[9], qb[4];
+            rot_to_quat(Rwc, q);
+            // camera world pose -> base_link world pose (M:160-172), through the quaternion as the reference does
+            quat_to_rot(q[0], q[1], q[2], q[3], Rq);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    Rwb[3 * r + c] = Rq[3 * r] * prm.b2c_R[3 * c] + Rq[3 * r + 1] * prm.b2c_R[3 * c + 1] + Rq[3 * r + 2] * prm.b2c_R[3 * c + 2];
+            for (int r = 0; r < 3; ++r)
+                pose[r] = twc[r] - (Rwb[3 * r] * prm.b2c_t[0] + Rwb[3 * r + 1] * prm.b2c_t[1] + Rwb[3 * r + 2] * prm.b2c_t[2]);
+            rot_to_quat(Rwb, qb);
+            pose[3] = qb[0]; pose[4] = qb[1]; pose[5] = qb[2]; pose[6] = qb[3];
         }
     }
-    if (best < 0) { out.outcome = RELOC_OUT_NO_PNP_ACCEPT; *res = out; return; }
-    for (int k = 0; k < 7; ++k) out.anchor_pose[k] = best_pose[k];
-    out.n_inl = best_inl;
-    out.reproj = best_err;
-    out.lm_idx = cand_ids[best];
-    const double dx = best_pose[0] - prm.base_pose[0], dy = best_pose[1] - prm.base_pose[1];
-    const double shift = sqrt(dx * dx + dy * dy);
-    out.outcome = (prm.check_consistency && shift > RELOC_CONSISTENCY_M) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
-    *res = out;
+    // best = max inliers, lowest slot on ties (`len(inliers) > best[0]`, M:379)
+    const int key = okc ? (inl << 6) | (63 - s) : -1;
+    int best = key;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d));
+    if (best < 0) {
+        if (s == 0) {
+            TickResult out;
+            for (int k = 0; k < 7; ++k) out.anchor_pose[k] = 0;
+            out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.pad = 0; out.n_features = nfeat; out.n_candidates = nc;
+            out.outcome = nfeat < RELOC_MIN_MATCHES ? RELOC_OUT_NO_FEATURES : (nc == 0 ? RELOC_OUT_NO_CANDIDATES : RELOC_OUT_NO_PNP_ACCEPT);
+            *res = out;
+        }
+        return;
+    }
+    if (key == best) {
+        TickResult out;
+        for (int k = 0; k < 7; ++k) out.anchor_pose[k] = pose[k];
+        out.n_inl = inl; out.reproj = err; out.lm_idx = cand_ids[s]; out.pad = 0; out.n_features = nfeat; out.n_candidates = nc;
+        const double dx = pose[0] - prm.base_pose[0], dy = pose[1] - prm.base_pose[1];
+        const double shift = sqrt(dx * dx + dy * dy);
+        out.outcome = (prm.check_consistency && shift > RELOC_CONSISTENCY_M) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
+        *res = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
