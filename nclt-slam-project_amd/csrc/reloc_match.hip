@@ -327,7 +327,8 @@ __global__ void k_knn2_merge(const u32 *__restrict__ part, int na, int nsplit, i
 // through the scalar cache; per A row a lane produces 8 distances packed into one 16-byte store,
 // so a wave writes 1 KiB of one output row per instruction (HBM-write-bound shape).
 // grid.x = column tiles of 2048 (4 waves x 64 lanes x 8), grid.y = row tiles of MAT_ROWS.
-constexpr int MAT_ROWS = 128;
+constexpr int MAT_ROWS = 128;      // row tile of the unaligned fallback kernel
+constexpr int MAT_UNIT_ROWS = 8;   // rows per work unit of the persistent kernel
 
 struct MatRows { uint4 a[4], b[4]; };   // four A rows (wave-uniform: lives in SGPRs)
 
@@ -343,47 +344,61 @@ __device__ __forceinline__ MatRows mat_load(const uint4 *__restrict__ A, int64_t
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_hamming_matrix(const uint4 *__restrict__ A, int64_t na,
-                                                        const uint4 *__restrict__ B, int64_t nb,
-                                                        uint16_t *__restrict__ out)
+// Persistent: the grid is sized to what is resident at once (a grid a few percent larger than that
+// runs a second, almost empty round and loses ~30 %).  A workgroup is bound to one column tile
+// (blockIdx % n_col_tiles) so its 8 x 256 B columns stay in registers, and takes the 8-row units
+// k, k + K, k + 2K, ... of that tile (K = workgroups per column tile): no atomics, no barriers.
+// FULL = every lane's 8 columns exist (all column tiles except possibly the last).
+template <bool FULL>
+__device__ __forceinline__ void matrix_body(const uint4 *__restrict__ A, int64_t na, const uint4 *__restrict__ B, int64_t nb,
+                                            uint16_t *__restrict__ out, int ct, int k0, int kstep, int n_units)
 {
-    const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t i0 = (int64_t)blockIdx.y * MAT_ROWS;
-    const int64_t i1 = i0 + MAT_ROWS < na ? i0 + MAT_ROWS : na;
+    const int64_t j0 = ((int64_t)ct * 256 + threadIdx.x) * 8;
     u32 b[8][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const int64_t j = j0 + c < nb ? j0 + c : nb - 1;
+        const int64_t j = FULL || j0 + c < nb ? j0 + c : nb - 1;
         const uint4 lo = B[2 * j], hi = B[2 * j + 1];
         b[c][0] = lo.x; b[c][1] = lo.y; b[c][2] = lo.z; b[c][3] = lo.w;
         b[c][4] = hi.x; b[c][5] = hi.y; b[c][6] = hi.z; b[c][7] = hi.w;
     }
-    if (j0 >= nb) return;
-    const bool full = j0 + 8 <= nb;
-    // software pipeline: the scalar fetch of rows i+4..i+7 is in flight while rows i..i+3 are
-    // computed, and the four 16-byte stores of a group stay outstanding into the next group.
-    MatRows nxt = mat_load(A, i0, na - 1);
-    for (int64_t i = i0; i < i1; i += 4) {
-        const MatRows cur = nxt;
-        nxt = mat_load(A, i + 4 < na ? i + 4 : na - 1, na - 1);
+    if (!FULL && j0 >= nb) return;
+    for (int unit = k0; unit < n_units; unit += kstep) {
+        const int64_t i0 = (int64_t)unit * MAT_UNIT_ROWS;
+        MatRows nxt = mat_load(A, i0, na - 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u32 w[4];
+        for (int g = 0; g < MAT_UNIT_ROWS; g += 4) {
+            const MatRows cur = nxt;
+            if (g + 4 < MAT_UNIT_ROWS) nxt = mat_load(A, i0 + g + 4, na - 1);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const u32 odd = ham8(b[2 * p + 1], cur.a[e], cur.b[e], 0);
-                w[p] = ham8(b[2 * p], cur.a[e], cur.b[e], odd << 16);
-            }
-            if (i + e < i1) {
-                uint16_t *o = out + (i + e) * nb + j0;
-                if (full) {
-                    *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
-                } else {
-                    for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
+            for (int e = 0; e < 4; ++e) {
+                u32 w[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const u32 odd = ham8(b[2 * p + 1], cur.a[e], cur.b[e], 0);
+                    w[p] = ham8(b[2 * p], cur.a[e], cur.b[e], odd << 16);
+                }
+                if (i0 + g + e < na) {
+                    uint16_t *o = out + (i0 + g + e) * nb + j0;
+                    if (FULL || j0 + 8 <= nb) {
+                        *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    } else {
+                        for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
+                    }
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint4 *__restrict__ A, int64_t na,
+                                                        const uint4 *__restrict__ B, int64_t nb,
+                                                        uint16_t *__restrict__ out, int n_col_tiles, int n_units)
+{
+    const int ct = blockIdx.x % n_col_tiles;
+    const int k0 = blockIdx.x / n_col_tiles, kstep = gridDim.x / n_col_tiles;
+    if ((int64_t)(ct + 1) * 2048 <= nb) matrix_body<true>(A, na, B, nb, out, ct, k0, kstep, n_units);
+    else matrix_body<false>(A, na, B, nb, out, ct, k0, kstep, n_units);
 }
 
 // slow path for outputs whose rows are not 16-byte aligned (nb % 8 != 0)
@@ -403,17 +418,43 @@ __global__ void k_hamming_matrix_any(const uint4 *__restrict__ A, int64_t na, co
 static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb, uint16_t *out)
 {
     if (na <= 0 || nb <= 0) return RELOC_OK;
-    const int64_t gy = (na + MAT_ROWS - 1) / MAT_ROWS;
-    if (gy > 65535 * 16) { reloc_set_error("hamming matrix: too many rows"); return RELOC_E_CAPACITY; }
-    reloc_prof_begin(ctx, RELOC_PROF_MATRIX);
     if (nb % 8 == 0 && ((uintptr_t)out & 15) == 0) {
-        dim3 grid((unsigned)((nb + 2047) / 2048), (unsigned)gy);
-        hipLaunchKernelGGL(k_hamming_matrix, grid, dim3(256), 0, ctx->stream, (const uint4 *)a, na, (const uint4 *)b, nb, out);
+        const int n_col_tiles = (int)((nb + 2047) / 2048);
+        const int64_t n_units = (na + MAT_UNIT_ROWS - 1) / MAT_UNIT_ROWS;
+        if (n_col_tiles > 4096 || n_units > 0x7fffffff) { reloc_set_error("hamming matrix: shape too large"); return RELOC_E_CAPACITY; }
+        static int per_cu = 0;
+        if (!per_cu) {
+            // blocks of 4 waves = one wave per SIMD each: residency = waves per SIMD the register
+            // allocation admits, capped by the occupancy query (which can over-report by one)
+            hipFuncAttributes fa;
+            int api = 0;
+            per_cu = 4;
+            if (hipFuncGetAttributes(&fa, (const void *)k_hamming_matrix) == hipSuccess && fa.numRegs > 0) {
+                const int alloc = (fa.numRegs + 7) / 8 * 8;
+                per_cu = 512 / alloc < 8 ? 512 / alloc : 8;
+            }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k_hamming_matrix, 256, 0) == hipSuccess && api > 0 && api < per_cu)
+                per_cu = api;
+            if (per_cu > 6) per_cu = 6;
+            if (per_cu < 1) per_cu = 1;
+        }
+        int grid = ctx->num_cu * per_cu;
+        grid = grid / n_col_tiles * n_col_tiles;
+        if (grid < n_col_tiles) grid = n_col_tiles;
+        const int64_t cap = n_units * n_col_tiles;
+        if (grid > cap) grid = (int)cap;
+        reloc_prof_begin(ctx, RELOC_PROF_MATRIX);
+        hipLaunchKernelGGL(k_hamming_matrix, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)a, na, (const uint4 *)b, nb,
+                           out, n_col_tiles, (int)n_units);
+        reloc_prof_end(ctx, RELOC_PROF_MATRIX);
     } else {
+        const int64_t gy = (na + MAT_ROWS - 1) / MAT_ROWS;
+        if (gy > 65535) { reloc_set_error("hamming matrix: too many rows for the unaligned path"); return RELOC_E_CAPACITY; }
+        reloc_prof_begin(ctx, RELOC_PROF_MATRIX);
         dim3 grid((unsigned)((nb + 255) / 256), (unsigned)gy);
         hipLaunchKernelGGL(k_hamming_matrix_any, grid, dim3(256), 0, ctx->stream, (const uint4 *)a, na, (const uint4 *)b, nb, out);
+        reloc_prof_end(ctx, RELOC_PROF_MATRIX);
     }
-    reloc_prof_end(ctx, RELOC_PROF_MATRIX);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
