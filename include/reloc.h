@@ -169,6 +169,7 @@ int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t
  * exchanges the per-shard top-k (count, global id) lists and tells each rank which of ITS
  * records made the global top-k.  These two calls split reloc_tick_dev at that exchange. */
 int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order,
+                        const double base_pose[7] /* NULL: no heading mask */,
                         int32_t *topk_ids_dev, int32_t *topk_counts_dev, int k);
 int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand,
                          const double base_pose[7], int check_consistency, uint64_t seed);

@@ -357,8 +357,8 @@ RELOC_API int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int o
 }
 
 // ---- sharded database: scan and solve halves ------------------------------------------------------
-RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, int32_t *topk_ids_dev,
-                                  int32_t *topk_counts_dev, int k)
+RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
+                                  int32_t *topk_ids_dev, int32_t *topk_counts_dev, int k)
 {
     ARG_CHECK(ctx && img_dev && topk_ids_dev && topk_counts_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64,
               "reloc_tick_scan_dev");
@@ -367,9 +367,10 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
     if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) return rc;
     double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
-    const TickParams prm = make_tick_params(ctx, zero_pose, 1, 0);
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_counts, (const double *)nullptr, prm, k, 0,
-                       topk_ids_dev, topk_counts_dev, ctx->cand_n);
+    const TickParams prm = make_tick_params(ctx, base_pose ? base_pose : zero_pose, 1, 0);
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_counts,
+                       base_pose ? (const double *)ctx->db_xy_heading : (const double *)nullptr, prm, k, 0, topk_ids_dev,
+                       topk_counts_dev, ctx->cand_n);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }

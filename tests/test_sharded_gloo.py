@@ -1,0 +1,131 @@
+"""Sharded database, N > 1 path on CPU: two gloo ranks, each owning half of the records, must produce
+exactly what one rank owning everything produces (candidate merge order, winner, pose)."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleShard:
+    """oracle-backed stand-in for HipShard (test infrastructure): same scan / solve contract."""
+
+    def __init__(self, data, a, b):
+        import math
+        from oracle_backend import oracle_cv2
+        from nclt_slam_project_amd.matcher import LandmarkMatcherCore, MatcherConfig
+        self.cv2 = oracle_cv2()
+        self.core = LandmarkMatcherCore({**data, "landmarks": data["landmarks"][a:b]}, cv2=self.cv2,
+                                        config=MatcherConfig(global_reloc=True))
+        self.n_records = b - a
+        self.math = math
+
+    def scan(self, frame, base_pose, k):
+        gray = self.cv2.cvtColor(frame, self.cv2.COLOR_BGR2GRAY)
+        kps, desc = self.core.orb.detectAndCompute(gray, None)
+        self.desc = desc
+        self.pts2d = np.array([kp.pt for kp in kps], dtype=np.float32)
+        herr = self.core.heading_errors(base_pose)
+        scored = []
+        for li in np.where(herr < self.math.radians(90.0))[0]:
+            d = self.core.landmarks[li]["descriptors"]
+            if d is None or len(d) < 10:
+                continue
+            n = len(self.core.matcher.match(d, desc))
+            if n >= 10:
+                scored.append((n, int(li)))
+        scored.sort(reverse=True)
+        ids = np.full(k, -1, np.int32); cnt = np.zeros(k, np.int32)
+        for i, (n, li) in enumerate(scored[:k]):
+            ids[i] = li; cnt[i] = n
+        return ids, cnt
+
+    def solve(self, local_ids, base_pose, check_consistency, seed):
+        best = None
+        for li in local_ids:
+            r = self.core.solve_candidate(int(li), self.desc, self.pts2d, relocating=True)
+            if r is not None and (best is None or r[0] > best[0]):
+                best = (*r, int(li))
+        if best is None:
+            return dict(outcome=3, n_inliers=0, reproj=0.0, anchor_pose=np.zeros(7), lm_idx=-1)
+        return dict(outcome=0, n_inliers=best[0], reproj=best[1], anchor_pose=np.array(best[2]), lm_idx=best[3])
+
+
+def _database():
+    from nclt_slam_project_amd import synth
+    from nclt_slam_project_amd.recorder import LandmarkRecorderCore
+    from nclt_slam_project_amd import landmarks as LM
+    from oracle_backend import oracle_cv2
+    scene = synth.WallScene()
+    rec = LandmarkRecorderCore(cv2=oracle_cv2())
+    for x in (2.0, 4.5, 7.0, 9.5):
+        bp = synth.base_pose(x, 0.0, 0.0)
+        bgr, dep = scene.render(bp)
+        rec.tick(bgr, dep, bp, x)
+    data = rec.database()
+    # pad with random records so the shards are not trivially small and the merge has to interleave
+    rng = np.random.default_rng(3)
+    desc, pts, off, poses = synth.descriptor_db(rng, 8, "ragged")
+    extra = LM.unpack_landmarks(desc, pts, off, poses)
+    lms = []
+    for i in range(4):
+        lms += [extra[2 * i], data["landmarks"][i], extra[2 * i + 1]]
+    data["landmarks"] = lms
+    return data, scene
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nclt_slam_project_amd import landmarks as LM, synth
+    from nclt_slam_project_amd.sharded import ShardedRelocalizer
+    data, scene = _database()
+    _, _, off, _ = LM.pack_landmarks(data["landmarks"])
+    bounds = LM.shard_by_rows(off, world)
+    a, b = int(bounds[rank]), int(bounds[rank + 1])
+    sr = ShardedRelocalizer(OracleShard(data, a, b), a, rank, world)
+    results = []
+    for pose in [(5.0, 9.0, 2.0), (4.6, 0.25, 3.0), (6.0, -9.5, -3.0)]:
+        bp = synth.base_pose(*pose)
+        r = sr.tick(scene.render(bp)[0], bp)
+        results.append(dict(outcome=r["outcome"], n_inliers=r["n_inliers"], lm_idx=r["lm_idx"],
+                            anchor=[float(v) for v in r["anchor_pose"]], n_candidates=r["n_candidates"]))
+    if rank == 0:
+        json.dump(dict(bounds=[int(x) for x in bounds], results=results), open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_rank_gloo_equals_single_rank(oracle, tmp_path):
+    from nclt_slam_project_amd import synth
+    from nclt_slam_project_amd.sharded import ShardedRelocalizer, merge_topk
+    out = str(tmp_path / "r.json")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = json.load(open(out))
+    assert 0 < got["bounds"][1] < 12
+    data, scene = _database()
+    single = ShardedRelocalizer(OracleShard(data, 0, len(data["landmarks"])), 0, 0, 1)
+    for pose, g in zip([(5.0, 9.0, 2.0), (4.6, 0.25, 3.0), (6.0, -9.5, -3.0)], got["results"]):
+        bp = synth.base_pose(*pose)
+        e = single.tick(scene.render(bp)[0], bp)
+        assert g["outcome"] == e["outcome"] and g["n_inliers"] == e["n_inliers"] and g["lm_idx"] == e["lm_idx"]
+        assert g["n_candidates"] == e["n_candidates"]
+        np.testing.assert_allclose(g["anchor"], e["anchor_pose"], atol=1e-12)
+    assert any(r["outcome"] == 0 for r in got["results"])
+    # merge rule: (count desc, id desc), -1 padding ignored
+    ids, cnt = merge_topk([[5, 1, -1], [9, 7, 2]], [[30, 12, 0], [30, 12, 40]], k=4)
+    assert list(ids) == [2, 9, 5, 7] and list(cnt) == [40, 30, 30, 12]
