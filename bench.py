@@ -96,6 +96,18 @@ def cpu_baseline(frames, db, sample_records):
                 cpu=_cpu_model(), host_cores=os.cpu_count())
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r1/summary.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, handled as MI355X_MICROARCH.md's HBM section prescribes); None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1", "summary.json")))[kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+    # streaming 16-B/lane pattern (matrix kernel): FETCH_SIZE is doubled, WRITE_SIZE exact; the scan kernel reads through
+    # scalar loads, for which the counter is uncalibrated: its raw value is used (lower bound)
+    return d["hbm_bytes_upper"] if kernel == "k_hamming_matrix" else d["hbm_bytes_lower"]
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -197,7 +209,7 @@ def main():
         # (profiles/ubench_valu_r1.log); 1024 SIMDs at 2.4 GHz
         valu_peak_pairs = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2)
         roofline = dict(kernel="k_db_scan", bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
-                        frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=None,
+                        frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=pmc_traffic("k_db_scan"),
                         avg_launch_us=scan_s * 1e6, launches=scan_n, algorithmic_bytes=alg_bytes,
                         note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %",
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
@@ -223,7 +235,7 @@ def main():
             mb = 32 * (F + K) + 2 * F * K
             ms = m_ms / max(m_n, 1) * 1e-3
             roofline_matrix = dict(kernel="k_hamming_matrix", shape=[F, K], bound="hbm", achieved=mb / ms / 1e9, peak=8000.0,
-                                   unit="GB/s", frac=mb / ms / 1e9 / 8000.0, traffic=None, avg_launch_us=ms * 1e6,
+                                   unit="GB/s", frac=mb / ms / 1e9 / 8000.0, traffic=pmc_traffic("k_hamming_matrix"), avg_launch_us=ms * 1e6,
                                    launches=m_n, algorithmic_bytes=mb)
             for p in (a, b, out):
                 e.dev_free(p)
