@@ -121,9 +121,9 @@ def _cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--frames-per-step", type=int, default=64)
     ap.add_argument("--records", type=int, default=10000)
     ap.add_argument("--rows", default="fixed64", help="fixed64 | ragged | <int>")
     ap.add_argument("--streams", type=int, default=4)
@@ -205,16 +205,18 @@ def main():
         alg_bytes = 32 * T + 32 * Q + 4 * L               # database once, queries once, one count per record
         scan_s = scan_ms / max(scan_n, 1) * 1e-3
         pairs = T * Q
-        # VALU issue floor of the distance itself: 8 v_xor (~2.5 cyc) + 8 v_bcnt (~4.2 cyc) per 64 pairs per SIMD
-        # (profiles/ubench_valu_r1.log); 1024 SIMDs at 2.4 GHz
-        valu_peak_pairs = 1024 * 2.4e9 * 64 / (8 * 2.5 + 8 * 4.2)
+        # VALU ceiling of the distance itself, measured: 8 x (v_xor_b32 v,s,v ; v_bcnt_u32_b32 acc) per pair reaches
+        # 2.60 T pairs/s at 8 waves/SIMD and 2.3 T at 4 (profiles/ubench_chain_r1.log); v_bcnt is a half-rate instruction
+        valu_peak_pairs = 2.60e12
         roofline = dict(kernel="k_db_scan", bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
                         frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=pmc_traffic("k_db_scan"),
                         avg_launch_us=scan_s * 1e6, launches=scan_n, algorithmic_bytes=alg_bytes,
                         note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %",
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
                                   frac=pairs / scan_s / valu_peak_pairs,
-                                  basis="8 v_xor_b32 + 8 v_bcnt_u32_b32 per 256-bit pair at the measured issue rates"))
+                                  basis="measured chip ceiling of 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair "
+                                        "(tools/ubench_chain.hip); the kernel issues 22.4 VALU instructions per pair-row instead of 16 "
+                                        "(argmin bookkeeping) at 4 waves/SIMD"))
         stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan=scan_s * 1e6, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
         roofline_matrix = None
         if not args.no_matrix:

@@ -24,6 +24,8 @@
 // emits the per-record count and optionally the (queryIdx, trainIdx, distance) list in queryIdx
 // order.  Keys are (distance << k | index): the minimum of packed keys is the smallest distance
 // with the LOWEST index on ties, which is the tie rule of the specification.
+#include <stdlib.h>
+
 #include "reloc_internal.h"
 
 typedef uint32_t u32;
@@ -120,18 +122,18 @@ __device__ __forceinline__ u32 rows_min16(u32 (&d)[16], int lane)
 constexpr int SCAN_CHUNK = 16;             // rows per chunk (4-bit row index inside the 16-bit key)
 constexpr u32 KEY_INVALID_BIAS = 512u;     // added to the distance of padding columns (> 256)
 
-// One 16-row chunk of a record against the wave's 512 columns.
-//   q[j]    : descriptor of column j*64 + lane (+ colbase); bias[j] = 0 or KEY_INVALID_BIAS
+// One 16-row chunk of a record against the wave's 64*NJ columns.
+//   q[j]    : descriptor of column colbase + j*64 + lane; bias[j] = 0 or KEY_INVALID_BIAS
 //   CLAMP   : tail chunk, row indices clamped to the record's last row (a duplicate row offers
 //             the same distance with a larger index, so it never wins a minimum)
-template <bool CLAMP>
-__device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[8][8],
-                                           const u32 (&bias)[8], u32 colbase, u32 *rowkey, u32 *colbest,
+template <int NJ, bool CLAMP>
+__device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[NJ][8],
+                                           const u32 (&bias)[NJ], u32 colbase, u32 *rowkey, u32 *colbest,
                                            bool single_cb, int lane)
 {
-    u32 cb16[8];
+    u32 cb16[NJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cb16[j] = 0xFFFFu;
+    for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
     u32 rk[SCAN_CHUNK];
 #pragma unroll
     for (int t = 0; t < SCAN_CHUNK; t += 2) {
@@ -147,7 +149,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         for (int e = 0; e < 2; ++e) {
             u32 best = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
+            for (int j = 0; j < NJ; j += 2) {
                 u32 h0, h1;
                 ham8x2(q[j], q[j + 1], a[e], b[e], bias[j], bias[j + 1], h0, h1);
                 const u32 kd0 = shl4_u16(h0), kd1 = shl4_u16(h1);          // (d << 4), 16 bit
@@ -167,15 +169,21 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         else atomicMin(&rowkey[row], m);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const u32 key = ((cb16[j] >> 4) << 16) | (u32)(tc + (int)(cb16[j] & 15u));
         atomicMin(&colbest[colbase + j * 64 + lane], key);
     }
 }
 
-// grid: any; block: 256 (4 waves).  Dynamic LDS: (ncb*512 + max_rows + 16) * 4 bytes.
-template <bool EMIT>
-__global__ __launch_bounds__(256, 4) void k_db_scan(
+// grid: any; block: 256 (4 waves).  Dynamic LDS: (ncb*64*NJ + max_rows + 16) * 4 bytes.
+// NJ = columns per lane.  A wave covers a "column block" of 64*NJ current descriptors.  When the
+// number of column blocks ncb divides 4, wave w is bound to block w % ncb for the whole launch (its
+// descriptors stay in registers) and takes the 16-row chunks w / ncb, w / ncb + 4 / ncb, ...;
+// otherwise every wave walks all column blocks and reloads its registers per block.
+// NJ = 8: 500 descriptors are one block (64 VGPRs of descriptors, 4 waves per SIMD);
+// NJ = 4: two blocks, ~64 VGPRs in total, 8 waves per SIMD.
+template <int NJ, bool EMIT>
+__global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
     const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
@@ -183,19 +191,20 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
     int32_t *__restrict__ m_n, int emit_stride)
 {
     extern __shared__ u32 lds[];
+    constexpr int CB = 64 * NJ;           // columns per block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row fetches stay scalar
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
     const int n_ids = n_ids_p ? min(*n_ids_p, n_ids_max) : n_ids_max;
-    const int ncb = max((C + 511) >> 9, 1);
-    u32 *colbest = lds;                   // ncb * 512 : best (distance << 16 | row) per column
-    u32 *rowkey = colbest + ncb * 512;    // max_rows  : best (distance << 16 | column) per row
+    const int ncb = max((C + CB - 1) / CB, 1);
+    u32 *colbest = lds;                   // ncb * CB : best (distance << 16 | row) per column
+    u32 *rowkey = colbest + ncb * CB;     // max_rows : best (distance << 16 | column) per row
     u32 *wsum = rowkey + max_rows;        // 16
 
-    u32 q[8][8], bias[8];
+    u32 q[NJ][8], bias[NJ];
     auto load_q = [&](int colbase) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int col = colbase + j * 64 + lane;
             if (col < C) {
                 const uint4 a = cur[2 * col], b = cur[2 * col + 1];
@@ -209,24 +218,27 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
             }
         }
     };
-    if (ncb == 1) load_q(0);
+    const bool bound = (4 % ncb) == 0;            // ncb in {1, 2, 4}: static wave -> column block binding
+    const int my_cb = bound ? wave % ncb : 0;
+    const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? 4 / ncb : 4;
+    if (bound) load_q(my_cb * CB);
 
     for (int it = blockIdx.x; it < n_ids; it += gridDim.x) {
         const int r = rec_ids ? rec_ids[it] : it;
         const int64_t row0 = off[r];
         const int n = (int)(off[r + 1] - row0);
         const uint4 *rec = db + 2 * row0;
-        for (int i = tid; i < ncb * 512; i += 256) colbest[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < ncb * CB; i += 256) colbest[i] = 0xFFFFFFFFu;
         for (int i = tid; i < n; i += 256) rowkey[i] = 0xFFFFFFFFu;
         __syncthreads();
         if (n > 0 && C > 0) {
-            for (int cb = 0; cb < ncb; ++cb) {
-                if (ncb > 1) load_q(cb * 512);
-                for (int tc = wave * SCAN_CHUNK; tc < n; tc += 4 * SCAN_CHUNK) {
+            for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
+                if (!bound) load_q(cb * CB);
+                for (int tc = chunk0 * SCAN_CHUNK; tc < n; tc += chunk_step * SCAN_CHUNK) {
                     if (tc + SCAN_CHUNK <= n)
-                        scan_chunk<false>(rec, n, tc, q, bias, (u32)(cb * 512), rowkey, colbest, ncb == 1, lane);
+                        scan_chunk<NJ, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                     else
-                        scan_chunk<true>(rec, n, tc, q, bias, (u32)(cb * 512), rowkey, colbest, ncb == 1, lane);
+                        scan_chunk<NJ, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                 }
             }
         }
@@ -266,6 +278,36 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
     }
 }
 
+static int g_scan_nj = 0;   // 0 = default; RELOC_SCAN_NJ=4|8 overrides (developer switch)
+
+template <int NJ>
+static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, const int32_t *rec_ids,
+                             const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur, const int32_t *n_cur_dev,
+                             int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx, int32_t *m_tidx, int32_t *m_dist,
+                             int32_t *m_n, int emit_stride)
+{
+    constexpr int CB = 64 * NJ;
+    const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
+    const size_t lds = (size_t)(ncb * CB + max_rows + 16) * 4;
+    if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
+    int per_cu = NJ == 4 ? 8 : 4;
+    const int lds_limit = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (per_cu > lds_limit) per_cu = lds_limit > 0 ? lds_limit : 1;
+    int grid = ctx->num_cu * per_cu;
+    if (grid > n_ids_max) grid = n_ids_max;
+    const bool emit = m_qidx != nullptr;
+    if (emit)
+        hipLaunchKernelGGL((k_db_scan<NJ, true>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+    else
+        hipLaunchKernelGGL((k_db_scan<NJ, false>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
@@ -274,23 +316,16 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (n_ids_max <= 0) return RELOC_OK;
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
-    const int ncb = (n_cur_max + 511) / 512 > 0 ? (n_cur_max + 511) / 512 : 1;
     if (max_rows < 1) max_rows = 1;
-    const size_t lds = (size_t)(ncb * 512 + max_rows + 16) * 4;
-    if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
-    int grid = ctx->num_cu * 4;
-    if (grid > n_ids_max) grid = n_ids_max;
-    const bool emit = m_qidx != nullptr;
-    if (emit)
-        hipLaunchKernelGGL(k_db_scan<true>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
-    else
-        hipLaunchKernelGGL(k_db_scan<false>, dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
-    HIP_TRY(hipGetLastError());
-    return RELOC_OK;
+    if (!g_scan_nj) {
+        const char *e = getenv("RELOC_SCAN_NJ");
+        g_scan_nj = (e && e[0] == '4') ? 4 : 8;
+    }
+    if (g_scan_nj == 4)
+        return launch_db_scan_nj<4>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows,
+                                    counts, m_qidx, m_tidx, m_dist, m_n, emit_stride);
+    return launch_db_scan_nj<8>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows, counts,
+                                m_qidx, m_tidx, m_dist, m_n, emit_stride);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-// Developer experiment: what binds the u16 distance-matrix kernel -- VALU or the store stream?
+// Developer experiment: persistent u16 distance-matrix kernel variants (columns per lane, rows buffered before storing).
 // hipcc --offload-arch=gfx950 -O3 -o tools/exp_matrix tools/exp_matrix.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -13,63 +13,68 @@ __device__ __forceinline__ u32 ham8(const u32 q[8], const uint4 a, const uint4 b
     acc = bcnt_acc(q[4] ^ b.x, acc); acc = bcnt_acc(q[5] ^ b.y, acc); acc = bcnt_acc(q[6] ^ b.z, acc); acc = bcnt_acc(q[7] ^ b.w, acc);
     return acc;
 }
-struct MatRows { uint4 a[4], b[4]; };
-__device__ __forceinline__ MatRows mat_load(const uint4 *__restrict__ A, int64_t i, int64_t last)
+// NJ columns per lane (4 or 8), G rows computed before their stores are issued (1, 2, 4, 8), UNIT rows per unit
+template <int NJ, int G, int UNIT, int MODE, int BS>
+__global__ __launch_bounds__(BS) void k(const uint4 *__restrict__ A, int64_t na, const uint4 *__restrict__ B, int64_t nb,
+                                         uint16_t *__restrict__ out, int n_col_tiles, int n_units)
 {
-    MatRows r;
+    const int ct = blockIdx.x % n_col_tiles;
+    const int k0 = blockIdx.x / n_col_tiles, kstep = gridDim.x / n_col_tiles;
+    const int64_t j0 = ((int64_t)ct * BS + threadIdx.x) * NJ;
+    u32 b[NJ][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int64_t ii = i + e < last ? i + e : last; r.a[e] = A[2 * ii]; r.b[e] = A[2 * ii + 1]; }
-    return r;
-}
-// MODE 0: full; 1: compute only (one store per block of rows, keeps values live); 2: store only (no distance work)
-template <int MODE, int ROWS, int NT>
-__global__ __launch_bounds__(256) void k(const uint4 *__restrict__ A, int64_t na, const uint4 *__restrict__ B, int64_t nb, uint16_t *__restrict__ out)
-{
-    const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t i0 = (int64_t)blockIdx.y * ROWS;
-    const int64_t i1 = i0 + ROWS < na ? i0 + ROWS : na;
-    u32 b[8][8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < NJ; ++c) {
         const int64_t j = j0 + c < nb ? j0 + c : nb - 1;
         const uint4 lo = B[2 * j], hi = B[2 * j + 1];
         b[c][0] = lo.x; b[c][1] = lo.y; b[c][2] = lo.z; b[c][3] = lo.w; b[c][4] = hi.x; b[c][5] = hi.y; b[c][6] = hi.z; b[c][7] = hi.w;
     }
     if (j0 >= nb) return;
-    MatRows nxt = mat_load(A, i0, na - 1);
     u32 keep = 0;
-    for (int64_t i = i0; i < i1; i += 4) {
-        const MatRows cur = nxt;
-        nxt = mat_load(A, i + 4 < na ? i + 4 : na - 1, na - 1);
+    for (int unit = k0; unit < n_units; unit += kstep) {
+        const int64_t i0 = (int64_t)unit * UNIT;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u32 w[4];
-            if (MODE == 2) { w[0] = cur.a[e].x ^ b[0][0]; w[1] = cur.a[e].y ^ b[1][0]; w[2] = cur.a[e].z; w[3] = cur.a[e].w; }
-            else {
+        for (int g = 0; g < UNIT; g += G) {
+            uint4 ra[G], rb[G];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) { const u32 odd = ham8(b[2 * p + 1], cur.a[e], cur.b[e], 0); w[p] = ham8(b[2 * p], cur.a[e], cur.b[e], odd << 16); }
-            }
-            if (MODE == 1) { keep ^= w[0] ^ w[1] ^ w[2] ^ w[3]; }
-            else if (i + e < i1) {
-                uint16_t *o = out + (i + e) * nb + j0;
-                if (NT) { typedef u32 v4 __attribute__((ext_vector_type(4))); v4 vv = {w[0], w[1], w[2], w[3]}; __builtin_nontemporal_store(vv, reinterpret_cast<v4 *>(o)); }
-                else *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int e = 0; e < G; ++e) { const int64_t ii = i0 + g + e < na ? i0 + g + e : na - 1; ra[e] = A[2 * ii]; rb[e] = A[2 * ii + 1]; }
+            u32 w[G][NJ / 2];
+#pragma unroll
+            for (int e = 0; e < G; ++e)
+#pragma unroll
+                for (int p = 0; p < NJ / 2; ++p) {
+                    if (MODE == 2) w[e][p] = ra[e].x ^ b[2 * p][0];
+                    else { const u32 odd = ham8(b[2 * p + 1], ra[e], rb[e], 0); w[e][p] = ham8(b[2 * p], ra[e], rb[e], odd << 16); }
+                }
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                if (MODE == 1) { for (int p = 0; p < NJ / 2; ++p) keep ^= w[e][p]; }
+                else if (i0 + g + e < na) {
+                    uint16_t *o = out + (i0 + g + e) * nb + j0;
+                    if (NJ == 8) *reinterpret_cast<uint4 *>(o) = make_uint4(w[e][0], w[e][1], w[e][2], w[e][3]);
+                    else *reinterpret_cast<uint2 *>(o) = make_uint2(w[e][0], w[e][1]);
+                }
             }
         }
     }
-    if (MODE == 1) out[(i0 * nb + j0)] = (uint16_t)keep;
+    if (MODE == 1) out[j0] = (uint16_t)keep;
 }
-template <int MODE, int ROWS, int NT> void run(const char *name, const uint4 *A, const uint4 *B, uint16_t *out, int64_t F, int64_t K)
+template <int NJ, int G, int UNIT, int MODE, int BS = 256> void run(const char *name, const uint4 *A, const uint4 *B, uint16_t *out, int64_t F, int64_t K, int per_cu)
 {
-    dim3 grid((unsigned)((K + 2047) / 2048), (unsigned)((F + ROWS - 1) / ROWS));
+    const int n_col_tiles = (int)((K + BS * NJ - 1) / (BS * NJ));
+    const int n_units = (int)((F + UNIT - 1) / UNIT);
+    int api = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k<NJ, G, UNIT, MODE, BS>, BS, 0);
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void *)k<NJ, G, UNIT, MODE, BS>);
+    if (per_cu <= 0) per_cu = api;
+    int grid = 256 * per_cu / n_col_tiles * n_col_tiles; if (grid < n_col_tiles) grid = n_col_tiles;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<MODE, ROWS, NT>), grid, dim3(256), 0, 0, A, F, B, K, out);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((k<NJ, G, UNIT, MODE, BS>), dim3(grid), dim3(BS), 0, 0, A, F, B, K, out, n_col_tiles, n_units);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<MODE, ROWS, NT>), grid, dim3(256), 0, 0, A, F, B, K, out);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<NJ, G, UNIT, MODE, BS>), dim3(grid), dim3(BS), 0, 0, A, F, B, K, out, n_col_tiles, n_units);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
-    printf("%-34s %8.1f us  %7.1f GB/s-equivalent  %6.2f T pairs/s\n", name, ms * 1e3, 2.0 * F * K / ms / 1e6, (double)F * K / ms / 1e9);
+    printf("%-30s regs=%3d api=%d per_cu=%d grid=%5d %8.1f us  %7.1f GB/s  %5.1f%%\n", name, fa.numRegs, api, per_cu, grid, ms * 1e3,
+           2.0 * F * K / ms / 1e6, 2.0 * F * K / ms / 1e6 / 80.0);
 }
 int main()
 {
@@ -79,13 +84,16 @@ int main()
     uint4 *A, *B; uint16_t *out;
     hipMalloc(&A, F * 32); hipMalloc(&B, K * 32); hipMalloc(&out, F * K * 2 + 4096);
     hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
-    run<0, 128, 0>("full rows=128", A, B, out, F, K);
-    run<0, 128, 1>("full rows=128 nontemporal", A, B, out, F, K);
-    run<0, 64, 0>("full rows=64", A, B, out, F, K);
-    run<0, 256, 0>("full rows=256", A, B, out, F, K);
-    run<0, 512, 1>("full rows=512 nontemporal", A, B, out, F, K);
-    run<1, 128, 0>("compute only rows=128", A, B, out, F, K);
-    run<2, 128, 0>("store only rows=128", A, B, out, F, K);
-    run<2, 128, 1>("store only rows=128 nontemporal", A, B, out, F, K);
+    run<8, 4, 16, 0, 256>("nj8 g4 u16 bs256", A, B, out, F, K, 0);
+    run<8, 4, 16, 0, 512>("nj8 g4 u16 bs512", A, B, out, F, K, 0);
+    run<8, 4, 16, 0, 1024>("nj8 g4 u16 bs1024", A, B, out, F, K, 0);
+    run<8, 2, 16, 0, 512>("nj8 g2 u16 bs512", A, B, out, F, K, 0);
+    run<8, 2, 16, 0, 1024>("nj8 g2 u16 bs1024", A, B, out, F, K, 0);
+    run<8, 4, 16, 2, 256>("store-only bs256", A, B, out, F, K, 0);
+    run<8, 4, 16, 2, 512>("store-only bs512", A, B, out, F, K, 0);
+    run<8, 4, 16, 2, 1024>("store-only bs1024", A, B, out, F, K, 0);
+    run<8, 4, 16, 2, 64>("store-only bs64", A, B, out, F, K, 0);
+    run<8, 4, 16, 0, 64>("nj8 g4 u16 bs64", A, B, out, F, K, 0);
+    run<8, 4, 16, 0, 128>("nj8 g4 u16 bs128", A, B, out, F, K, 0);
     return 0;
 }
