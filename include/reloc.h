@@ -100,6 +100,15 @@ const int32_t *reloc_frame_count_dev(reloc_ctx *ctx);     /* 1 x i32: number of 
  * what: 0 = pyramid level, 1 = blurred level, 2 = NMS-kept FAST score map. */
 int reloc_frame_debug_plane(reloc_ctx *ctx, int what, int level, uint8_t *out, int32_t *w, int32_t *h);
 
+/* Teach-side record builder (R:240-288): ORB on the frame, then per keypoint the border / ground masks,
+ * depth lookup (uint16 millimetres), 3x3 non-zero depth std, range and variance gates and pin-hole
+ * back-projection.  Outputs (up to max_feat rows, keypoint order kept): xy = keypoints_2d, desc =
+ * descriptors, pts3d = keypoints_3d_cam, kp_index = row in the frame's ORB output.  The caller applies
+ * the ">= 30 survivors" rule (R:270) and the displacement trigger. */
+int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint16_t *depth_mm, int w, int h, int order,
+                       int nfeatures, float *xy, uint8_t *desc, float *pts3d, int32_t *kp_index,
+                       int32_t *n_out, int32_t *n_kp);
+
 /* ---- 256-bit Hamming matching --------------------------------------------------------------- */
 /* cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(q, t)                  M:211,327  G:337
  * Mutual nearest neighbours, lowest index on ties, sorted by queryIdx.  Outputs sized min(nq,nt). */

@@ -1,0 +1,146 @@
+// reloc_record.hip -- teach-side record builder on gfx950.
+//
+// Serves VisualLandmarkRecorder._tick after ORB (reference R:247-288): keypoint rounding, border and
+// ground masks, depth lookup (mm -> m), 3x3 non-zero depth standard deviation, range / variance gates,
+// pin-hole back-projection.  The reference does this in NumPy with a Python loop per keypoint
+// (R:262-266); NumPy's arithmetic is the specification here, so every expression below mirrors the
+// NumPy dtype rules of the reference's lines:
+//   np.round(float32)            -> round half to even in float32
+//   depth.astype(float32)/1000.0 -> float32 division
+//   patch[patch > 0.01].std()    -> float32 pairwise sum (numpy's 8-accumulator tree for n >= 8,
+//                                   running sum from 0 for n < 8), mean, squared deviations, mean, sqrt
+//   (uu - CX) * d_c / FX         -> int32 - python float = float64, * float32 = float64, / float64,
+//                                   stacked with float32 z and cast to float32
+// One lane per keypoint; survivors are compacted in keypoint order by a block-wide scan.
+#include "reloc_internal.h"
+
+struct RecordParams {
+    double fx, fy, cx, cy;
+    float depth_min, depth_max, var_max;
+    int ground_y;
+    int w, h;
+};
+
+// float32 sum with numpy's pairwise order for n <= 9
+__device__ float np_sum9(const float *a, int n)
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+        return r;
+    }
+    float r = __fadd_rn(__fadd_rn(__fadd_rn(a[0], a[1]), __fadd_rn(a[2], a[3])),
+                        __fadd_rn(__fadd_rn(a[4], a[5]), __fadd_rn(a[6], a[7])));
+    for (int i = 8; i < n; ++i) r = __fadd_rn(r, a[i]);
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_record(const float *__restrict__ f_xy, const uint8_t *__restrict__ f_desc,
+                                                 const int32_t *__restrict__ f_count, int max_feat,
+                                                 const uint16_t *__restrict__ depth, int dstride, RecordParams p,
+                                                 float *__restrict__ o_xy, uint8_t *__restrict__ o_desc,
+                                                 float *__restrict__ o_pts, int32_t *__restrict__ o_idx,
+                                                 int32_t *__restrict__ o_n)
+{
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(*f_count, max_feat);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float x = 0, y = 0, dz = 0;
+        int u = 0, v = 0;
+        if (i < n) {
+            x = f_xy[2 * i]; y = f_xy[2 * i + 1];
+            u = (int)rintf(x); v = (int)rintf(y);
+            if (u >= 1 && u < p.w - 1 && v >= 1 && v < p.h - 1 && v > p.ground_y) {
+                dz = __fdiv_rn((float)depth[(size_t)v * dstride + u], 1000.0f);
+                float vals[9];
+                int cnt = 0;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float m = __fdiv_rn((float)depth[(size_t)(v + dy) * dstride + (u + dx)], 1000.0f);
+                        if (m > 0.01f) vals[cnt++] = m;
+                    }
+                float sd = 999.0f;
+                if (cnt >= 3) {
+                    const float mean = __fdiv_rn(np_sum9(vals, cnt), (float)cnt);
+                    float sq[9];
+                    for (int k = 0; k < cnt; ++k) { const float d = __fsub_rn(vals[k], mean); sq[k] = __fmul_rn(d, d); }
+                    sd = __fsqrt_rn(__fdiv_rn(np_sum9(sq, cnt), (float)cnt));
+                }
+                keep = dz > p.depth_min && dz < p.depth_max && sd < p.var_max;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += s_wsum[w];
+        if (keep) {
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            o_xy[2 * pos] = x; o_xy[2 * pos + 1] = y;
+            o_pts[3 * pos] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)u, p.cx), (double)dz), p.fx);
+            o_pts[3 * pos + 1] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)v, p.cy), (double)dz), p.fy);
+            o_pts[3 * pos + 2] = dz;
+            o_idx[pos] = i;
+            const uint4 *s = reinterpret_cast<const uint4 *>(f_desc + (size_t)i * 32);
+            uint4 *d = reinterpret_cast<uint4 *>(o_desc + (size_t)pos * 32);
+            d[0] = s[0]; d[1] = s[1];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) *o_n = s_base;
+}
+
+// Host-pointer entry point: ORB on the frame, then the gates.  Outputs hold up to the ctx's max_feat
+// rows: xy (n,2) f32 keypoints_2d, desc (n,32) u8, pts3d (n,3) f32 keypoints_3d_cam, kp_index (n) i32
+// (row of the surviving keypoint in the frame's ORB output); *n_out rows written, *n_kp = ORB keypoints.
+RELOC_API int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint16_t *depth_mm, int w, int h, int order,
+                                 int nfeatures, float *xy, uint8_t *desc, float *pts3d, int32_t *kp_index, int32_t *n_out,
+                                 int32_t *n_kp)
+{
+    ARG_CHECK(ctx && img && depth_mm && n_out && w >= 64 && h >= 64 && nfeatures > 0, "reloc_record_frame");
+    if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
+    *n_out = 0;
+    if (n_kp) *n_kp = 0;
+    int rc;
+    void *ddepth, *dout;
+    const int64_t mf = ctx->max_feat;
+    if ((rc = reloc_scratch(ctx, 5, (int64_t)w * h * 2, &ddepth))) return rc;
+    if ((rc = reloc_scratch(ctx, 6, mf * (8 + 32 + 12 + 4) + 64, &dout))) return rc;
+    uint8_t *o_desc = (uint8_t *)dout;
+    float *o_xy = (float *)(o_desc + mf * 32), *o_pts = o_xy + mf * 2;
+    int32_t *o_idx = (int32_t *)(o_pts + mf * 3), *o_n = o_idx + mf;
+    HIP_TRY(hipMemcpyAsync(ctx->frame_img, img, (size_t)w * h * 3, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ddepth, depth_mm, (size_t)w * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = orb_run_dev(ctx, ctx->frame_img, w, h, w * 3, 3, order, nfeatures))) return rc;
+    RecordParams p;
+    p.fx = ctx->K4[0]; p.fy = ctx->K4[1]; p.cx = ctx->K4[2]; p.cy = ctx->K4[3];
+    p.depth_min = RELOC_DEPTH_MIN_M; p.depth_max = RELOC_DEPTH_MAX_M; p.var_max = RELOC_DEPTH_VAR_MAX_M;
+    p.ground_y = RELOC_GROUND_Y_THRESHOLD; p.w = w; p.h = h;
+    hipLaunchKernelGGL(k_record, dim3(1), dim3(1024), 0, ctx->stream, ctx->f_xy, ctx->f_desc, ctx->f_count, ctx->max_feat,
+                       (const uint16_t *)ddepth, w, p, o_xy, o_desc, o_pts, o_idx, o_n);
+    HIP_TRY(hipGetLastError());
+    int32_t n = 0, nk = 0;
+    HIP_TRY(hipMemcpyAsync(&n, o_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&nk, ctx->f_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        if (xy) HIP_TRY(hipMemcpyAsync(xy, o_xy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, o_desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (pts3d) HIP_TRY(hipMemcpyAsync(pts3d, o_pts, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+        if (kp_index) HIP_TRY(hipMemcpyAsync(kp_index, o_idx, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n;
+    if (n_kp) *n_kp = nk;
+    return RELOC_OK;
+}

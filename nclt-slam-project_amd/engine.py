@@ -116,6 +116,22 @@ class Engine:
         return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=ang[:k].copy(), response=resp[:k].copy(),
                     octave=octv[:k].copy(), desc=desc[:k].copy(), n=k)
 
+    def record_frame(self, bgr: np.ndarray, depth_mm: np.ndarray, nfeatures: int = 500, order_rgb: bool = False):
+        """teach-side record arrays of one frame: dict(xy (n,2), desc (n,32), pts3d (n,3), kp_index (n,), n, n_kp)"""
+        bgr = N.u8(bgr)
+        depth_mm = np.ascontiguousarray(depth_mm, np.uint16)
+        h, w, _ = bgr.shape
+        if depth_mm.shape != (h, w):
+            raise N.RelocError("record_frame: depth and colour sizes differ")
+        mf = self.max_feat
+        xy = np.empty((mf, 2), np.float32); desc = np.empty((mf, 32), np.uint8); pts = np.empty((mf, 3), np.float32)
+        idx = np.empty(mf, np.int32); n = C.c_int32(); nk = C.c_int32()
+        N.check(self._lib.reloc_record_frame(self._ctx, N.ptr(bgr), N.ptr(depth_mm), w, h, int(order_rgb), int(nfeatures),
+                                             N.ptr(xy), N.ptr(desc), N.ptr(pts), N.ptr(idx), C.byref(n), C.byref(nk)),
+                "reloc_record_frame")
+        k = n.value
+        return dict(xy=xy[:k].copy(), desc=desc[:k].copy(), pts3d=pts[:k].copy(), kp_index=idx[:k].copy(), n=k, n_kp=nk.value)
+
     def frame_debug_plane(self, what: int, level: int) -> np.ndarray:
         buf = np.empty(self.max_w * self.max_h, np.uint8)
         w = C.c_int32(); h = C.c_int32()

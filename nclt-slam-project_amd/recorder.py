@@ -39,13 +39,17 @@ def local_depth_std(depth_mm, uu, vv):
 
 
 class LandmarkRecorderCore:
-    def __init__(self, out_pkl=None, min_disp_m: float = 2.0, cv2=None, nfeatures: int = 500, logger=None):
-        if cv2 is None:
+    def __init__(self, out_pkl=None, min_disp_m: float = 2.0, cv2=None, nfeatures: int = 500, logger=None, engine=None):
+        """engine: when given, ORB + all per-keypoint gates + back-projection run in ONE device call
+        (reloc_record_frame); otherwise the gates run in NumPy on the cv2-shaped module's features."""
+        self.engine = engine
+        self.nfeatures = nfeatures
+        if cv2 is None and engine is None:
             from . import cv2_shim as cv2
         self.cv2 = cv2
         self.out_pkl = out_pkl
         self.min_disp_m = float(min_disp_m)
-        self.orb = cv2.ORB_create(nfeatures=nfeatures)
+        self.orb = cv2.ORB_create(nfeatures=nfeatures) if cv2 is not None else None
         self.landmarks = []
         self.last_landmark_pose_world = None
         self.log = logger or (lambda msg: None)
@@ -59,6 +63,15 @@ class LandmarkRecorderCore:
             lx, ly = self.last_landmark_pose_world[0], self.last_landmark_pose_world[1]
             if math.hypot(cam_pose[0] - lx, cam_pose[1] - ly) < self.min_disp_m:
                 return None
+        if self.engine is not None:
+            r = self.engine.record_frame(bgr, depth_mm, self.nfeatures)
+            if r["n"] < MIN_RECORD_KPTS:
+                return None
+            rec = {"pose": cam_pose, "descriptors": r["desc"], "keypoints_2d": r["xy"], "keypoints_3d_cam": r["pts3d"],
+                   "ts": rgb_ts, "n_features": int(r["n"])}
+            self.landmarks.append(rec)
+            self.last_landmark_pose_world = cam_pose
+            return rec
         cv2 = self.cv2
         gray = cv2.cvtColor(bgr, cv2.COLOR_BGR2GRAY)
         kpts, desc = self.orb.detectAndCompute(gray, None)
