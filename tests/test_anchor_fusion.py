@@ -1,0 +1,57 @@
+"""CPU: the relay-side anchor consumer (section 8(f) row f3) and an end-to-end teach -> repeat -> fusion
+replay on the synthetic scene (oracle-backed features)."""
+import math
+
+import pytest
+
+from nclt_slam_project_amd import pose as P
+from nclt_slam_project_amd.anchor_fusion import AnchorFusion
+
+
+def test_regimes_and_weights():
+    f = AnchorFusion()
+    r = f.blend(0.0, (10.0, 0.0), (10.5, 0.0))
+    assert r.regime == "no_anchor" and r.alpha == 0.95 and r.anchor_staleness == -1.0
+    # silent > 10 s: SLAM weight follows the SLAM-encoder disagreement
+    for d, a in [(1.0, 0.95), (3.0, 0.70), (7.0, 0.40), (20.0, 0.10)]:
+        assert AnchorFusion().blend(100.0, (0.0, 0.0), (d, 0.0)).alpha == a
+    f.on_anchor(10.0, 1.0, 2.0, P.anchor_covariance(P.anchor_std(30))[0])       # std 0.05: strong, streak 1
+    assert f.regime(10.1) == "ok"                                               # hysteresis not yet met
+    f.on_anchor(10.5, 1.0, 2.0, 0.05 ** 2)
+    assert f.regime(10.6) == "strong"
+    r = f.blend(10.6, (2.0, 3.0), (4.0, 5.0))
+    assert r.x == pytest.approx(0.40 * 1.0 + 0.55 * 2.0 + 0.05 * 4.0) and r.y == pytest.approx(0.40 * 2 + 0.55 * 3 + 0.05 * 5)
+    f.on_anchor(11.0, 1.0, 2.0, 0.17 ** 2)                                      # weaker anchor: streak decays, "ok"
+    assert f.anchor_strong_streak == 1 and f.regime(11.1) == "ok"
+    r = f.blend(11.1, (2.0, 3.0), (4.0, 5.0))
+    assert r.x == pytest.approx(0.20 * 1.0 + 0.75 * 2.0 + 0.05 * 4.0)
+    f.on_anchor(12.0, 1.0, 2.0, 0.25 ** 2)                                      # std above OK: ignored
+    assert f.regime(12.1) == "no_anchor"
+    f.on_anchor(13.0, 1.0, 2.0, 0.05 ** 2)
+    assert f.regime(13.0 + 3.0) in ("ok", "strong") and f.regime(13.0 + 3.01) == "no_anchor"   # staleness bound
+    assert f.on_anchor(14.0, 0, 0, 0.0) == pytest.approx(1e-4)                 # std floor sqrt(1e-8)
+
+
+def test_replay_teach_repeat_fusion(oracle):
+    from oracle_backend import oracle_cv2
+    from nclt_slam_project_amd import synth
+    from nclt_slam_project_amd.matcher import LandmarkMatcherCore
+    from nclt_slam_project_amd.recorder import LandmarkRecorderCore
+    cv2 = oracle_cv2()
+    scene = synth.WallScene()
+    rec = LandmarkRecorderCore(cv2=cv2)
+    for x in (2.0, 4.5, 7.0):
+        bp = synth.base_pose(x, 0.0, 0.0)
+        bgr, dep = scene.render(bp)
+        rec.tick(bgr, dep, bp, x)
+    m = LandmarkMatcherCore(rec.database(), cv2=cv2)
+    f = AnchorFusion()
+    regimes = []
+    for i, (x, y, yaw) in enumerate([(2.3, -0.2, -2.0), (4.6, 0.25, 3.0), (6.8, 0.1, 1.0)]):
+        bp = synth.base_pose(x, y, yaw)
+        bgr, dep = scene.render(bp)
+        o = m.tick(bgr, dep, bp, ts=100.0 + 0.5 * i)
+        f.on_outcome(o)
+        regimes.append(f.blend(100.0 + 0.5 * i + 0.05, (x, y), (x + 0.1, y)).regime)
+    assert regimes[0] == "ok" and regimes[-1] == "strong"
+    assert math.isfinite(f.anchor_last[1])
