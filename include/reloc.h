@@ -109,6 +109,12 @@ int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint16_t *depth
                        int nfeatures, float *xy, uint8_t *desc, float *pts3d, int32_t *kp_index,
                        int32_t *n_out, int32_t *n_kp);
 
+/* Depth image -> obstacle points of the relay's depth_cb (scripts/common/tf_wall_clock_relay_v55.py:1020-1038):
+ * every `step`-th pixel with zmin < z < zmax, point = (z, -(u-cx)/fx*z, -(v-cy)/fy*z) f32, raster order.
+ * depth: float32 metres (is_f32) or uint16 millimetres; points holds ceil(w/step)*ceil(h/step) x 3. */
+int reloc_depth_points(reloc_ctx *ctx, const void *depth, int is_f32, int w, int h, int step, const double K4[4],
+                       float zmin, float zmax, float *points, int32_t *n_out);
+
 /* ---- 256-bit Hamming matching --------------------------------------------------------------- */
 /* cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(q, t)                  M:211,327  G:337
  * Mutual nearest neighbours, lowest index on ties, sorted by queryIdx.  Outputs sized min(nq,nt). */
@@ -130,6 +136,10 @@ int64_t reloc_db_rows(reloc_ctx *ctx);
 int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts);
 int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, const int32_t *n_cur_dev,
                               int n_cur_max, int32_t *counts_dev);
+/* Ratio-test score of every record: number of current descriptors whose two nearest rows of the record
+ * satisfy d1 < ratio * d2 -- knnMatch(desc_cur, desc_record, k=2) + Lowe test of the archived anchor
+ * localizers (_archive/anchor_localizer.py:82-90, ratio 0.75) and the self-test (S:68-71, 0.80). */
+int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, double ratio, int32_t *counts);
 /* All-pairs u16 distance matrix (loop-closure sweep shape; no reference counterpart,
  * BASELINE.json config 5): out[i * nb + j] = hamming(a_i, b_j). */
 int reloc_hamming_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,

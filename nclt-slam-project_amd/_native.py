@@ -41,6 +41,8 @@ SIGNATURES = {
     "reloc_frame_count_dev": (P, [c_ctx]),
     "reloc_frame_debug_plane": (C.c_int, [c_ctx, C.c_int, C.c_int, P, P, P]),
     "reloc_record_frame": (C.c_int, [c_ctx, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P]),
+    "reloc_depth_points": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, C.c_int, P, f32, f32, P, P]),
+    "reloc_db_ratio_counts": (C.c_int, [c_ctx, P, C.c_int, f64, P]),
     "reloc_match_mutual": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, P, P, P, P]),
     "reloc_match_knn2": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, P, P]),
     "reloc_db_upload": (C.c_int, [c_ctx, P, P, P, P, i64]),

@@ -278,6 +278,103 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ratio-test score of every record (reference _archive/anchor_localizer.py:82-90,
+// checkpoint_a_selftest.py:68-71): per record, the number of current descriptors whose two nearest rows
+// of the record satisfy d1 < ratio * d2.  Same data flow as k_db_scan (512 current descriptors per wave
+// in registers, teach rows through the scalar cache) but the epilogue only tracks the two smallest
+// distances per column: v_max_u16 + 2 v_min_u16 per pair, no indices, no cross-lane work in the loop.
+__device__ __forceinline__ u32 max_u16(u32 a, u32 b)
+{
+    u32 r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
+                                                     const uint4 *__restrict__ cur, const int32_t *__restrict__ n_cur_p,
+                                                     int n_cur_max, double ratio, int32_t *__restrict__ counts)
+{
+    __shared__ u32 s_part[4][512];
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
+    const int ncb = max((C + 511) >> 9, 1);
+    u32 q[8][8];
+    auto load_q = [&](int colbase) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = min(colbase + j * 64 + lane, max(C - 1, 0));
+            const uint4 a = cur[2 * col], b = cur[2 * col + 1];
+            q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+            q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
+        }
+    };
+    if (ncb == 1 && C > 0) load_q(0);
+    for (int r = blockIdx.x; r < n_rec; r += gridDim.x) {
+        const int64_t row0 = off[r];
+        const int n = (int)(off[r + 1] - row0);
+        const uint4 *rec = db + 2 * row0;
+        int good = 0;
+        if (n >= 2 && C > 0) {
+            for (int cb = 0; cb < ncb; ++cb) {
+                if (ncb > 1) load_q(cb * 512);
+                u32 k0[8], k1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { k0[j] = 0xFFFFu; k1[j] = 0xFFFFu; }
+                for (int t0 = wave * 8; t0 < n; t0 += 32) {
+#pragma unroll
+                    for (int t = 0; t < 8; t += 2) {
+                        uint4 a[2], b[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int rr = min(t0 + t + e, n - 1);      // a duplicate of the last row must not count twice:
+                            a[e] = rec[2 * rr];                          // handled below by skipping rows >= n
+                            b[e] = rec[2 * rr + 1];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (t0 + t + e < n) {                        // wave-uniform
+#pragma unroll
+                                for (int j = 0; j < 8; j += 2) {
+                                    u32 h0, h1;
+                                    ham8x2(q[j], q[j + 1], a[e], b[e], 0, 0, h0, h1);
+                                    const u32 m0 = max_u16(k0[j], h0), m1 = max_u16(k0[j + 1], h1);
+                                    k0[j] = min_u16(k0[j], h0); k0[j + 1] = min_u16(k0[j + 1], h1);
+                                    k1[j] = min_u16(k1[j], m0); k1[j + 1] = min_u16(k1[j + 1], m1);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s_part[wave][j * 64 + lane] = (k1[j] << 16) | k0[j];
+                __syncthreads();
+                for (int c = tid; c < 512; c += 256) {
+                    u32 a0 = 0xFFFFu, a1 = 0xFFFFu;
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 v = s_part[w][c];
+                        const u32 lo = v & 0xFFFFu, hi = v >> 16;
+                        // merge two sorted pairs: smallest two of {a0, a1, lo, hi}
+                        const u32 n0 = a0 < lo ? a0 : lo;
+                        const u32 n1 = a0 < lo ? (a1 < lo ? a1 : lo) : (hi < a0 ? hi : a0);
+                        a0 = n0; a1 = n1;
+                    }
+                    const bool ok = cb * 512 + c < C && a1 != 0xFFFFu && (double)a0 < ratio * (double)a1;
+                    good += __popcll(__ballot(ok));
+                }
+                __syncthreads();
+            }
+        }
+        // every lane of a wave holds that wave's total; sum the four waves
+        if (lane == 0) s_cnt[wave] = good;
+        __syncthreads();
+        if (tid == 0) counts[r] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+}
+
 static int g_scan_nj = 0;   // 0 = default; RELOC_SCAN_NJ=4|8 overrides (developer switch)
 
 template <int NJ>
@@ -698,6 +795,26 @@ RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, 
                             n_cur_dev, n_cur_max, ctx->db_max_rows, counts_dev, nullptr, nullptr, nullptr, nullptr, 0);
     reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
     return rc;
+}
+
+RELOC_API int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, double ratio, int32_t *counts)
+{
+    ARG_CHECK(ctx && counts && n_cur >= 0 && (n_cur == 0 || cur) && ratio > 0, "reloc_db_ratio_counts");
+    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
+    if (n_cur > 65535) { reloc_set_error("ratio scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
+    void *dc;
+    int rc;
+    if ((rc = reloc_scratch(ctx, 0, (int64_t)n_cur * 32, &dc))) return rc;
+    HIP_TRY(hipMemcpyAsync(dc, cur, (size_t)n_cur * 32, hipMemcpyHostToDevice, ctx->stream));
+    int grid = ctx->num_cu * 4;
+    if (grid > ctx->db_records) grid = (int)ctx->db_records;
+    hipLaunchKernelGGL(k_db_ratio, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)ctx->db_desc, ctx->db_off,
+                       (int)ctx->db_records, (const uint4 *)dc, (const int32_t *)nullptr, n_cur, ratio, ctx->db_counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts, ctx->db_counts, (size_t)ctx->db_records * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RELOC_OK;
 }
 
 RELOC_API int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts)

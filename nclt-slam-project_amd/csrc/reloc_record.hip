@@ -144,3 +144,78 @@ RELOC_API int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint1
     if (n_kp) *n_kp = nk;
     return RELOC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Depth image -> obstacle point cloud (reference relay depth_cb,
+// tf_wall_clock_relay_v55.py:1020-1038): every `step`-th pixel, keep 0.3 < z < 10 and finite,
+// point = (z, -(u - cx) / fx * z, -(v - cy) / fy * z) in float32, raster order.
+__global__ __launch_bounds__(1024) void k_depth_points(const void *__restrict__ depth, int is_f32, int w, int h, int dstride_px,
+                                                       int step, float cx, float cy, float fx, float fy, float zmin, float zmax,
+                                                       float *__restrict__ out, int32_t *__restrict__ o_n)
+{
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gw = (w + step - 1) / step, gh = (h + step - 1) / step;
+    const int n = gw * gh;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float z = 0;
+        int u = 0, v = 0;
+        if (i < n) {
+            v = (i / gw) * step; u = (i % gw) * step;
+            if (is_f32) z = reinterpret_cast<const float *>(depth)[(size_t)v * dstride_px + u];
+            else z = __fdiv_rn((float)reinterpret_cast<const uint16_t *>(depth)[(size_t)v * dstride_px + u], 1000.0f);
+            keep = z > zmin && z < zmax && isfinite(z);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int k = 0; k < wave; ++k) before += s_wsum[k];
+        int total = 0;
+        for (int k = 0; k < 16; ++k) total += s_wsum[k];
+        if (keep) {
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            const float px = __fmul_rn(__fdiv_rn(__fsub_rn((float)u, cx), fx), z);
+            const float py = __fmul_rn(__fdiv_rn(__fsub_rn((float)v, cy), fy), z);
+            out[3 * pos] = z; out[3 * pos + 1] = -px; out[3 * pos + 2] = -py;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) *o_n = s_base;
+}
+
+// depth: (h, w) float32 metres (is_f32 = 1) or uint16 millimetres (is_f32 = 0), dense rows.
+// points must hold ceil(w/step) * ceil(h/step) rows of 3 floats.
+RELOC_API int reloc_depth_points(reloc_ctx *ctx, const void *depth, int is_f32, int w, int h, int step, const double K4[4],
+                                 float zmin, float zmax, float *points, int32_t *n_out)
+{
+    ARG_CHECK(ctx && depth && points && n_out && w > 0 && h > 0 && step > 0 && K4, "reloc_depth_points");
+    if ((int64_t)w * h > (int64_t)ctx->max_w * ctx->max_h) { reloc_set_error("depth image exceeds ctx capacity"); return RELOC_E_CAPACITY; }
+    const int64_t npt = (int64_t)((w + step - 1) / step) * ((h + step - 1) / step);
+    void *ddepth, *dout;
+    int rc;
+    const int esz = is_f32 ? 4 : 2;
+    if ((rc = reloc_scratch(ctx, 5, (int64_t)w * h * esz, &ddepth))) return rc;
+    if ((rc = reloc_scratch(ctx, 6, npt * 12 + 16, &dout))) return rc;
+    int32_t *o_n = (int32_t *)((char *)dout + npt * 12);
+    HIP_TRY(hipMemcpyAsync(ddepth, depth, (size_t)w * h * esz, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_depth_points, dim3(1), dim3(1024), 0, ctx->stream, (const void *)ddepth, is_f32, w, h, w, step,
+                       (float)K4[2], (float)K4[3], (float)K4[0], (float)K4[1], zmin, zmax, (float *)dout, o_n);
+    HIP_TRY(hipGetLastError());
+    int32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, o_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(points, dout, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n;
+    return RELOC_OK;
+}

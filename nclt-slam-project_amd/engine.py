@@ -191,6 +191,27 @@ class Engine:
         N.check(self._lib.reloc_db_match_counts_dev(self._ctx, C.c_void_p(cur_dev), C.c_void_p(n_cur_dev), int(n_cur),
                                                     C.c_void_p(counts_dev)), "reloc_db_match_counts_dev")
 
+    def db_ratio_counts(self, cur, ratio: float = 0.75):
+        """per record: current descriptors passing the k=2 Lowe ratio test against the record's rows"""
+        cur = self._desc(cur, "db_ratio_counts") if len(cur) else np.zeros((0, 32), np.uint8)
+        counts = np.empty(self.db_records, np.int32)
+        N.check(self._lib.reloc_db_ratio_counts(self._ctx, N.ptr(cur), len(cur), float(ratio), N.ptr(counts)),
+                "reloc_db_ratio_counts")
+        return counts
+
+    def depth_points(self, depth, step: int = 4, K4=K4_DEFAULT, zmin: float = 0.3, zmax: float = 10.0):
+        """(n, 3) float32 obstacle points (z, -x, -y) of every step-th valid depth pixel, raster order"""
+        depth = np.ascontiguousarray(depth)
+        if depth.dtype not in (np.float32, np.uint16) or depth.ndim != 2:
+            raise N.RelocError("depth_points: expected an (H, W) float32 (metres) or uint16 (millimetres) image")
+        h, w = depth.shape
+        K4 = np.ascontiguousarray(K4, np.float64)
+        pts = np.empty((-(-w // step) * -(-h // step), 3), np.float32)
+        n = C.c_int32()
+        N.check(self._lib.reloc_depth_points(self._ctx, N.ptr(depth), int(depth.dtype == np.float32), w, h, int(step), N.ptr(K4),
+                                             float(zmin), float(zmax), N.ptr(pts), C.byref(n)), "reloc_depth_points")
+        return pts[: n.value].copy()
+
     def hamming_matrix(self, a, b):
         a = self._desc(a, "hamming_matrix"); b = self._desc(b, "hamming_matrix")
         out = np.empty((len(a), len(b)), np.uint16)

@@ -326,3 +326,12 @@ def rodrigues_log(R):
     r = np.zeros(3, np.float64)
     lib().orc_rodrigues_log(_p(R), _p(r))
     return r
+
+
+def db_ratio_counts(db, offsets, cur, ratio):
+    db = _u8(db); cur = _u8(cur)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    n_rec = len(offsets) - 1
+    counts = np.zeros(n_rec, np.int32)
+    lib().orc_db_ratio_counts(_p(db), _p(offsets), C.c_int64(n_rec), _p(cur), cur.shape[0], C.c_double(ratio), _p(counts))
+    return counts

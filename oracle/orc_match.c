@@ -138,3 +138,32 @@ ORC_API int orc_topk_records(const int32_t *counts, int64_t n_rec, int min_count
     *n_out = n;
     return 0;
 }
+
+/* Ratio-test score of every record: the archived anchor localizers and the
+ * self-test count, per teach record, the current descriptors whose two nearest rows of the record
+ * satisfy d1 < ratio * d2 -- `knnMatch(desc_cur, descriptors[aid], k=2)`, `len(pair) == 2 and
+ * pair[0].distance < ratio * pair[1].distance`
+ * (simulation/isaac/scripts/_archive/anchor_localizer.py:82-90,
+ *  experiments/55_visual_teach_repeat/scripts/checkpoint_a_selftest.py:68-71).
+ * Distances are ints cast to float by OpenCV; the product is evaluated in double like Python does. */
+ORC_API int orc_db_ratio_counts(const uint8_t *db, const int64_t *offsets, int64_t n_rec, const uint8_t *cur,
+                                int n_cur, double ratio, int32_t *counts)
+{
+    for (int64_t r = 0; r < n_rec; ++r) {
+        const uint8_t *t = db + 32 * offsets[r];
+        const int nt = (int)(offsets[r + 1] - offsets[r]);
+        int good = 0;
+        if (nt >= 2)
+            for (int i = 0; i < n_cur; ++i) {
+                int d0 = 1 << 30, d1 = 1 << 30;
+                for (int j = 0; j < nt; ++j) {
+                    int d = ham256(cur + 32 * (size_t)i, t + 32 * (size_t)j);
+                    if (d < d0) { d1 = d0; d0 = d; }
+                    else if (d < d1) d1 = d;
+                }
+                good += (double)d0 < ratio * (double)d1;
+            }
+        counts[r] = good;
+    }
+    return 0;
+}
