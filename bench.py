@@ -34,7 +34,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 640, 480
+W, H = 640, 480          # --size 720p switches to the 1280x720 characterisation shape (BASELINE.json config 3)
 SEED = 20260501 + 1          # seed = 20260501 + config index
 
 
@@ -127,9 +127,13 @@ def main():
     ap.add_argument("--records", type=int, default=10000)
     ap.add_argument("--rows", default="fixed64", help="fixed64 | ragged | <int>")
     ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--size", default="480p", choices=["480p", "720p"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true")
     args = ap.parse_args()
+    global W, H
+    if args.size == "720p":
+        W, H = 1280, 720
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,7 +253,7 @@ def main():
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"640x480 BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
+            "config": {"workload": f"{W}x{H} BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
                                    f"top-25 PnP-RANSAC(200)",
                        "frames_per_step": B, "streams": args.streams, "records": L, "descriptors": T,

@@ -264,3 +264,21 @@ def test_cv2_shim_surface(oracle):
     np.testing.assert_allclose(cv2.Rodrigues(R)[0].ravel(), r.ravel(), atol=1e-9)
     ok, _, _, inl = cv2.solvePnPRansac(obj[:3], imgp[:3], K, None)
     assert not ok and inl is None
+
+
+def test_selftest_harness_passes_on_own_teach_frames(oracle):
+    """checkpoint-A protocol (S:196-198): records self-localise within 0.3 m from their own frames"""
+    from oracle_backend import oracle_cv2
+    from nclt_slam_project_amd.selftest import selftest
+    cv2 = oracle_cv2()
+    scene = synth.WallScene()
+    rec = LandmarkRecorderCore(cv2=cv2)
+    frames = []
+    for x in (2.0, 4.5, 7.0, 9.5):
+        bp = synth.base_pose(x, 0.0, 0.0)
+        bgr, dep = scene.render(bp)
+        if rec.tick(bgr, dep, bp, x) is not None:
+            frames.append(bgr)
+    ok, s = selftest([(f, i) for i, f in enumerate(frames)], rec.database(), cv2)
+    assert ok and s["n"] == 4 and s["n_within"] == 4
+    assert all(r[0] == r[1] and r[2] > 100 for r in s["rows"])      # each frame picks its own record
