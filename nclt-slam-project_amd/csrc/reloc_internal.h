@@ -122,6 +122,8 @@ struct reloc_ctx {
     double *db_pose = nullptr;
     double *db_xy_heading = nullptr; // L x 4 (x, y, cos heading, sin heading) for candidate selection
     int32_t *db_counts = nullptr;    // L per-record mutual counts
+    int32_t *pool_ids = nullptr;     // L ids of the heading-compatible records of the current tick
+    int32_t *pool_n = nullptr;       // 1
 
     // ---- tick state ----
     int32_t *cand_ids = nullptr;     // MAX_CAND

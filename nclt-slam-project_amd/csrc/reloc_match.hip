@@ -757,7 +757,7 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     ARG_CHECK(n_records == 0 || poses, "poses missing");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     void **olds[] = {(void **)&ctx->db_desc, (void **)&ctx->db_pts3d, (void **)&ctx->db_off, (void **)&ctx->db_pose,
-                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts};
+                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts, (void **)&ctx->pool_ids, (void **)&ctx->pool_n};
     for (void **p : olds) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
     HIP_TRY(hipMalloc((void **)&ctx->db_desc, (size_t)(T > 0 ? T : 1) * 32));
     HIP_TRY(hipMalloc((void **)&ctx->db_pts3d, (size_t)(T > 0 ? T : 1) * 12));
@@ -765,6 +765,8 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     HIP_TRY(hipMalloc((void **)&ctx->db_pose, (size_t)(n_records > 0 ? n_records : 1) * 56));
     HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 32));
     HIP_TRY(hipMalloc((void **)&ctx->db_counts, (size_t)(n_records > 0 ? n_records : 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ctx->pool_ids, (size_t)(n_records > 0 ? n_records : 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ctx->pool_n, 16));
     if (T > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_desc, desc, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->db_pts3d, pts3d, (size_t)T * 12, hipMemcpyHostToDevice, ctx->stream));

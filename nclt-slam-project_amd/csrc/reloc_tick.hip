@@ -169,6 +169,43 @@ __global__ __launch_bounds__(1024) void k_topk_counts(const int32_t *__restrict_
     if (tid == 0) *out_n = n;
 }
 
+// ---- heading pool (G:329-330) ---------------------------------------------------------------------
+// ids of the heading-compatible records, ascending (block-wide ordered compaction), and zeroed counts:
+// the whole-database scan then only visits records the reference would score.
+__global__ __launch_bounds__(1024) void k_heading_pool(const double *__restrict__ xyh, TickParams prm, int32_t *__restrict__ ids,
+                                                       int32_t *__restrict__ n_out, int32_t *__restrict__ counts)
+{
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = prm.n_records;
+    double cc, sc;
+    cur_heading(prm, cc, sc);
+    const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < L; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        if (i < L) {
+            counts[i] = 0;
+            keep = heading_ok(xyh + 4 * i, cc, sc, cos_tol);
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += s_wsum[w];
+        if (keep) ids[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = s_base;
+}
+
 // ---- gather (M:333-336) ---------------------------------------------------------------------------
 // grid MAX_CAND, block 256: obj = keypoints_3d_cam[queryIdx], img = pts_curr_2d[trainIdx]
 __global__ __launch_bounds__(256) void k_gather(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
@@ -319,7 +356,15 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
     const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, !global_reloc);
     hipStream_t st = ctx->stream;
     if (global_reloc) {
-        if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) return rc;
+        // G:329-344: only heading-compatible records are scored
+        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(1024), 0, st, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
+                           ctx->db_counts);
+        reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
+        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
+                            ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr,
+                            nullptr, 0);
+        reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, st, ctx->db_counts, ctx->db_xy_heading, prm,
                            RELOC_GLOBAL_MAX_CANDIDATES, 0, ctx->cand_ids, (int32_t *)nullptr, ctx->cand_n);
     } else {
@@ -365,9 +410,20 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
     if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
-    if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) return rc;
     double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
     const TickParams prm = make_tick_params(ctx, base_pose ? base_pose : zero_pose, 1, 0);
+    if (base_pose) {
+        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
+                           ctx->db_counts);
+        reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
+        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
+                            ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr,
+                            nullptr, 0);
+        reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+        if (rc) return rc;
+    } else if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) {
+        return rc;
+    }
     hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_counts,
                        base_pose ? (const double *)ctx->db_xy_heading : (const double *)nullptr, prm, k, 0, topk_ids_dev,
                        topk_counts_dev, ctx->cand_n);
