@@ -103,30 +103,37 @@ __device__ __forceinline__ u32 bfly(u32 a, u32 b, int lane)
     }
 }
 
-// Reduce 16 vectors (one value per lane each) to one: afterwards lane l holds the minimum over
-// all 64 lanes of vector (l mod 16).
-__device__ __forceinline__ u32 rows_min16(u32 (&d)[16], int lane)
+// Reduce R vectors (one value per lane each, R = 4, 8 or 16) to one: afterwards lane l holds the
+// minimum over all 64 lanes of vector (l mod R).
+template <int R>
+__device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
 {
+    if constexpr (R >= 16) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = bfly<8>(d[i], d[i + 8], lane);
+        for (int i = 0; i < 8; ++i) d[i] = bfly<8>(d[i], d[i + 8], lane);
+    }
+    if constexpr (R >= 8) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = bfly<4>(d[i], d[i + 4], lane);
+        for (int i = 0; i < 4; ++i) d[i] = bfly<4>(d[i], d[i + 4], lane);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) d[i] = bfly<2>(d[i], d[i + 2], lane);
     u32 x = bfly<1>(d[0], d[1], lane);
+    if constexpr (R <= 4) x = umin(x, (u32)__shfl_xor((int)x, 4));
+    if constexpr (R <= 8) x = umin(x, (u32)__shfl_xor((int)x, 8));
     x = umin(x, (u32)__shfl_xor((int)x, 16));
     x = umin(x, (u32)__shfl_xor((int)x, 32));
     return x;
 }
 
-constexpr int SCAN_CHUNK = 16;             // rows per chunk (4-bit row index inside the 16-bit key)
+constexpr int SCAN_CHUNK = 16;             // largest chunk (4-bit row index inside the 16-bit key)
 constexpr u32 KEY_INVALID_BIAS = 512u;     // added to the distance of padding columns (> 256)
 
-// One 16-row chunk of a record against the wave's 64*NJ columns.
+// One R-row chunk (R = 16 or 4) of a record against the wave's 64*NJ columns.
 //   q[j]    : descriptor of column colbase + j*64 + lane; bias[j] = 0 or KEY_INVALID_BIAS
 //   CLAMP   : tail chunk, row indices clamped to the record's last row (a duplicate row offers
 //             the same distance with a larger index, so it never wins a minimum)
-template <int NJ, bool CLAMP>
+template <int NJ, int R, bool CLAMP>
 __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[NJ][8],
                                            const u32 (&bias)[NJ], u32 colbase, u32 *rowkey, u32 *colbest,
                                            bool single_cb, int lane)
@@ -134,9 +141,9 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     u32 cb16[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
-    u32 rk[SCAN_CHUNK];
+    u32 rk[R];
 #pragma unroll
-    for (int t = 0; t < SCAN_CHUNK; t += 2) {
+    for (int t = 0; t < R; t += 2) {
         int r[2];
         uint4 a[2], b[2];
 #pragma unroll
@@ -162,9 +169,9 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
             rk[t + e] = ((best >> 4) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
         }
     }
-    const u32 m = rows_min16(rk, lane);
-    const int row = tc + (lane & (SCAN_CHUNK - 1));
-    if (lane < SCAN_CHUNK && row < n) {
+    const u32 m = rows_min<R>(rk, lane);
+    const int row = tc + (lane & (R - 1));
+    if (lane < R && row < n) {
         if (single_cb) rowkey[row] = m;
         else atomicMin(&rowkey[row], m);
     }
@@ -234,11 +241,23 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
         if (n > 0 && C > 0) {
             for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
                 if (!bound) load_q(cb * CB);
-                for (int tc = chunk0 * SCAN_CHUNK; tc < n; tc += chunk_step * SCAN_CHUNK) {
-                    if (tc + SCAN_CHUNK <= n)
-                        scan_chunk<NJ, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                    else
-                        scan_chunk<NJ, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                // 16-row chunks when they deal out evenly over the waves bound to this column block, 4-row
+                // chunks otherwise (a 45-row record is 3 x 16 -> one of 4 waves idle, but 12 x 4 -> 3 each)
+                const int n16 = (n + 15) >> 4;
+                if (n16 % chunk_step == 0) {
+                    for (int tc = chunk0 * 16; tc < n; tc += chunk_step * 16) {
+                        if (tc + 16 <= n)
+                            scan_chunk<NJ, 16, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                        else
+                            scan_chunk<NJ, 16, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                    }
+                } else {
+                    for (int tc = chunk0 * 4; tc < n; tc += chunk_step * 4) {
+                        if (tc + 4 <= n)
+                            scan_chunk<NJ, 4, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                        else
+                            scan_chunk<NJ, 4, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                    }
                 }
             }
         }
