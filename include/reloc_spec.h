@@ -87,5 +87,6 @@
 #define RELOC_LM_MAX_TRIALS      30
 #define RELOC_LM_LAMBDA0         1e-3
 #define RELOC_LM_STEP_EPS        1e-10
+#define RELOC_LM_COST_EPS        1e-13        /* stop when |cost change| <= this * cost */
 
 #endif /* RELOC_SPEC_H */

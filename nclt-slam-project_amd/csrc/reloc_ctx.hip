@@ -50,7 +50,7 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->cand_cnt, NLEV);
     rc |= dalloc(&c->cand_key, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
     rc |= dalloc(&c->cand_resp, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
-    rc |= dalloc(&c->kp_cnt, NLEV + 1);
+    rc |= dalloc(&c->kp_cnt, NLEV);
     rc |= dalloc(&c->kp_key, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
     rc |= dalloc(&c->kp_resp, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
     rc |= dalloc(&c->f_xy, mf * 2);
@@ -76,7 +76,6 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->p_inl, (int64_t)MAX_CAND * MAX_REC_ROWS);
     rc |= dalloc(&c->p_out, MAX_CAND);
     rc |= dalloc(&c->tick_res, 1);
-    rc |= dalloc(&c->tick_pose, 8);
     return rc;
 }
 
@@ -127,7 +126,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
                     c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_off,
                     c->db_pose, c->db_xy_heading, c->db_counts, c->pool_ids, c->pool_n, c->cand_ids, c->cand_n, c->m_qidx,
                     c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
-                    c->p_out, c->tick_res, c->tick_pose};
+                    c->p_out, c->tick_res};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < 8; ++i)

@@ -88,13 +88,13 @@ struct reloc_ctx {
     int64_t pyr_bytes = 0;
     uint8_t *pyr = nullptr;        // pyramid levels
     uint8_t *blur = nullptr;       // blurred levels
-    uint8_t *nms = nullptr;        // NMS-kept score maps (debug tap + stage-1 source)
+    uint8_t *nms = nullptr;        // NMS-kept FAST score maps (stage-1 source, parity tap)
     int32_t *rz_tab = nullptr;     // resize tables (device)
     int32_t *hist = nullptr;       // NLEV x 256 score histograms
     int32_t *cand_cnt = nullptr;   // NLEV counters (stage-1 list sizes)
     uint32_t *cand_key = nullptr;  // NLEV x STAGE1_CAP packed (y<<16|x)
     float *cand_resp = nullptr;    // NLEV x STAGE1_CAP Harris responses
-    int32_t *kp_cnt = nullptr;     // NLEV kept counts + [NLEV] total
+    int32_t *kp_cnt = nullptr;     // NLEV kept counts
     uint32_t *kp_key = nullptr;    // NLEV x STAGE1_CAP kept keypoints (raster order per level)
     float *kp_resp = nullptr;
     // frame feature outputs (max_feat rows)
@@ -102,7 +102,6 @@ struct reloc_ctx {
     int32_t *f_oct = nullptr;
     uint8_t *f_desc = nullptr;
     int32_t *f_count = nullptr;
-    uint8_t *frame_gray = nullptr; // unused when level 0 is written directly
     uint8_t *frame_img = nullptr;  // staging for host frames (max_w*max_h*3)
     void *orb_const = nullptr;     // device copy of the OrbTable (reloc_orb.hip)
     char orb_tab_host[1024];       // host copy of the same table
@@ -135,7 +134,6 @@ struct reloc_ctx {
     int32_t *p_inl = nullptr;        // MAX_CAND x MAX_REC_ROWS
     PnpOut *p_out = nullptr;         // MAX_CAND
     TickResult *tick_res = nullptr;  // 1
-    double *tick_pose = nullptr;     // 7 (base pose of the current tick, device)
 };
 
 int reloc_scratch(reloc_ctx *ctx, int slot, int64_t bytes, void **out);

@@ -500,16 +500,17 @@ __global__ __launch_bounds__(64) void k_pnp_finish(const float *__restrict__ obj
         const double cn = lm_normal_wave(o, im, inl, n, Rn, prm.K4, Hn, gn);
         double step = 0;
         for (int a = 0; a < 6; ++a) if (fabs(dx[a]) > step) step = fabs(dx[a]);
+        const bool tiny = cn == cn && fabs(cn - cost) <= RELOC_LM_COST_EPS * (cost > 1e-300 ? cost : 1e-300);
         if (cn == cn && cn <= cost) {
             for (int k = 0; k < 12; ++k) Rt[k] = Rn[k];
             for (int k = 0; k < 21; ++k) H[k] = Hn[k];
             for (int k = 0; k < 6; ++k) g[k] = gn[k];
             cost = cn;
             lambda *= 0.1; if (lambda < 1e-12) lambda = 1e-12;
-            if (step < RELOC_LM_STEP_EPS) break;
+            if (step < RELOC_LM_STEP_EPS || tiny) break;
         } else {
             lambda *= 10.0;
-            if (step < RELOC_LM_STEP_EPS) break;
+            if (step < RELOC_LM_STEP_EPS || tiny) break;
         }
     }
     // mean inlier reprojection error under the refined pose (reference M:353-356)
