@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--rows", default="fixed64", help="fixed64 | ragged | <int>")
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--size", default="480p", choices=["480p", "720p"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --rehearse runs N ranks on one GPU")
+    ap.add_argument("--rehearse", action="store_true", help="developer rehearsal: every rank uses device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true")
     args = ap.parse_args()
@@ -141,12 +143,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nclt_slam_project_amd.engine import Engine
 
@@ -183,7 +190,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     outcomes = {}
