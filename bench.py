@@ -108,6 +108,57 @@ def pmc_traffic(kernel):
     return d["hbm_bytes_upper"] if kernel == "k_hamming_matrix" else d["hbm_bytes_lower"]
 
 
+def bench_sharded(args, rank, world, local_rank, dist, torch):
+    """Strong scaling of the whole-database search: every rank sees every frame, owns 1/world of the records."""
+    from nclt_slam_project_amd.engine import Engine
+    from nclt_slam_project_amd.sharded import HipShard, ShardedRelocalizer
+    e = Engine(local_rank, W, H, 2048)
+    frames, db, base_poses = build_workload(e, args.records, args.rows, 8)
+    shard = HipShard(e, *db, rank=rank, world=world, w=W, h=H)
+    dev = None if (dist is None or args.backend != "nccl") else torch.device("cuda", local_rank)
+    sr = ShardedRelocalizer(shard, shard.base, rank, world, device=dev)
+    frames_dev = [e.to_device(f) for f in frames]
+    B = args.frames_per_step
+
+    def step(s0):
+        out = None
+        for i in range(B):
+            out = sr.tick(frames_dev[i % 8], base_poses[i % 8], seed=s0 + i)
+        return out
+
+    for w_ in range(args.warmup):
+        step(0)
+    e.sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = step(k * B)
+    e.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    e.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        L = len(db[2]) - 1
+        print(json.dumps({
+            "metric": "relocalization frames/sec, database sharded by record", "value": B * args.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} frames, {L}-record DB split over {world} rank(s), per frame: ORB on every rank, shard scan, "
+                                   f"all-gather of top-25 (400 B), PnP on the owners, all-gather of the result (96 B)",
+                       "frames_per_step": B, "records": L, "shard_records": shard.n_records},
+            "last_outcome": int(last["outcome"]), "last_inliers": int(last["n_inliers"])}))
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -128,6 +179,9 @@ def main():
     ap.add_argument("--rows", default="fixed64", help="fixed64 | ragged | <int>")
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--size", default="480p", choices=["480p", "720p"])
+    ap.add_argument("--shard-db", action="store_true",
+                    help="BASELINE config 4 shape: ONE frame stream, the database split by record over the ranks, per frame an\n"
+                         "all-gather of the per-shard top-25 (not the judged default; reports its own JSON line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo + --rehearse runs N ranks on one GPU")
     ap.add_argument("--rehearse", action="store_true", help="developer rehearsal: every rank uses device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,6 +210,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nclt_slam_project_amd.engine import Engine
+
+    if args.shard_db:
+        return bench_sharded(args, rank, world, local_rank, dist, torch)
 
     engines = [Engine(local_rank, W, H, 2048) for _ in range(args.streams)]
     n_distinct = 8
