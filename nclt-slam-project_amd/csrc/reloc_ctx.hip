@@ -145,14 +145,14 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
 
 RELOC_API int reloc_set_stream(reloc_ctx *c, void *hip_stream)
 {
-    ARG_CHECK(c, "ctx is NULL");
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RELOC_OK;
 }
 
 RELOC_API int reloc_sync(reloc_ctx *c)
 {
-    ARG_CHECK(c, "ctx is NULL");
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RELOC_OK;
 }
@@ -171,35 +171,35 @@ RELOC_API void *reloc_dev_alloc(reloc_ctx *c, int64_t bytes)
 
 RELOC_API int reloc_dev_free(reloc_ctx *c, void *p)
 {
-    ARG_CHECK(c, "ctx is NULL");
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
     if (p) HIP_TRY(hipFree(p));
     return RELOC_OK;
 }
 
 RELOC_API int reloc_h2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
 {
-    ARG_CHECK(c && dst && src && bytes >= 0, "reloc_h2d");
+    ARG_CHECK_CTX(c, dst && src && bytes >= 0, "reloc_h2d");
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     return RELOC_OK;
 }
 
 RELOC_API int reloc_d2h(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
 {
-    ARG_CHECK(c && dst && src && bytes >= 0, "reloc_d2h");
+    ARG_CHECK_CTX(c, dst && src && bytes >= 0, "reloc_d2h");
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     return RELOC_OK;
 }
 
 RELOC_API int reloc_timer_begin(reloc_ctx *c)
 {
-    ARG_CHECK(c, "ctx is NULL");
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
     HIP_TRY(hipEventRecord(c->t0, c->stream));
     return RELOC_OK;
 }
 
 RELOC_API int reloc_timer_end(reloc_ctx *c, float *ms)
 {
-    ARG_CHECK(c && ms, "reloc_timer_end");
+    ARG_CHECK_CTX(c, ms, "reloc_timer_end");
     HIP_TRY(hipEventRecord(c->t1, c->stream));
     HIP_TRY(hipEventSynchronize(c->t1));
     HIP_TRY(hipEventElapsedTime(ms, c->t0, c->t1));
@@ -259,7 +259,7 @@ void reloc_prof_end(reloc_ctx *c, int which)
 
 RELOC_API int reloc_profile_enable(reloc_ctx *c, int on)
 {
-    ARG_CHECK(c, "ctx is NULL");
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
     for (int k = 0; k < RELOC_PROF_N; ++k) {
         prof_flush(c, k);
         c->prof[k].total = 0.f;
@@ -271,7 +271,7 @@ RELOC_API int reloc_profile_enable(reloc_ctx *c, int on)
 
 RELOC_API int reloc_profile_get(reloc_ctx *c, int which, float *total_ms, int32_t *launches)
 {
-    ARG_CHECK(c && which >= 0 && which < RELOC_PROF_N && total_ms && launches, "reloc_profile_get");
+    ARG_CHECK_CTX(c, which >= 0 && which < RELOC_PROF_N && total_ms && launches, "reloc_profile_get");
     prof_flush(c, which);
     *total_ms = c->prof[which].total;
     *launches = c->prof[which].launches;

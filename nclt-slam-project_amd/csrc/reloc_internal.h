@@ -30,6 +30,17 @@ void reloc_set_error(const char *fmt, ...);
         }                                                    \
     } while (0)
 
+// argument check of an entry point that takes a ctx: also makes the ctx's device current, so one process
+// may drive several GPUs through several ctxs
+#define ARG_CHECK_CTX(c, cond, msg)                           \
+    do {                                                      \
+        if (!(c) || !(cond)) {                                \
+            reloc_set_error("bad argument: %s", msg);         \
+            return RELOC_E_ARG;                               \
+        }                                                     \
+        (void)hipSetDevice((c)->device);                      \
+    } while (0)
+
 constexpr int NLEV = RELOC_ORB_NLEVELS;
 constexpr int MAX_REC_ROWS = 4096;   // largest record (teach rows) the fused scan accepts
 constexpr int MAX_CAND = 32;         // PnP candidates per tick (5 local / 25 global)

@@ -636,7 +636,7 @@ static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uin
 RELOC_API int reloc_hamming_matrix_dev(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,
                                        uint16_t *out)
 {
-    ARG_CHECK(ctx && a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix_dev");
+    ARG_CHECK_CTX(ctx, a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix_dev");
     ARG_CHECK((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "descriptor arrays must be 16-byte aligned");
     return launch_matrix(ctx, a, na, b, nb, out);
 }
@@ -644,7 +644,7 @@ RELOC_API int reloc_hamming_matrix_dev(reloc_ctx *ctx, const uint8_t *a, int64_t
 RELOC_API int reloc_hamming_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uint8_t *b, int64_t nb,
                                    uint16_t *out)
 {
-    ARG_CHECK(ctx && a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix");
+    ARG_CHECK_CTX(ctx, a && b && out && na >= 0 && nb >= 0, "reloc_hamming_matrix");
     if (na == 0 || nb == 0) return RELOC_OK;
     void *da, *db, *dout;
     int rc;
@@ -662,7 +662,7 @@ RELOC_API int reloc_hamming_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na,
 RELOC_API int reloc_match_knn2(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx,
                                int32_t *dist)
 {
-    ARG_CHECK(ctx && nq >= 0 && nt >= 0 && (nq == 0 || (q && idx && dist)) && (nt == 0 || t), "reloc_match_knn2");
+    ARG_CHECK_CTX(ctx, nq >= 0 && nt >= 0 && (nq == 0 || (q && idx && dist)) && (nt == 0 || t), "reloc_match_knn2");
     if (nq == 0) return RELOC_OK;
     if (nt == 0) {
         for (int i = 0; i < 2 * nq; ++i) { idx[i] = -1; dist[i] = -1; }
@@ -697,7 +697,7 @@ RELOC_API int reloc_match_knn2(reloc_ctx *ctx, const uint8_t *q, int nq, const u
 RELOC_API int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *qidx,
                                  int32_t *tidx, int32_t *dist, int32_t *n_out)
 {
-    ARG_CHECK(ctx && n_out && nq >= 0 && nt >= 0, "reloc_match_mutual");
+    ARG_CHECK_CTX(ctx, n_out && nq >= 0 && nt >= 0, "reloc_match_mutual");
     *n_out = 0;
     if (nq == 0 || nt == 0) return RELOC_OK;
     ARG_CHECK(q && t && qidx && tidx && dist, "reloc_match_mutual: NULL array");
@@ -762,7 +762,7 @@ int db_reindex(reloc_ctx *ctx)
 RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const int64_t *offsets,
                               const double *poses, int64_t n_records)
 {
-    ARG_CHECK(ctx && offsets && n_records >= 0, "reloc_db_upload");
+    ARG_CHECK_CTX(ctx, offsets && n_records >= 0, "reloc_db_upload");
     const int64_t T = offsets[n_records];
     ARG_CHECK(offsets[0] == 0 && T >= 0, "offsets must start at 0 and be non-decreasing");
     int maxrows = 0;
@@ -809,7 +809,7 @@ RELOC_API int64_t reloc_db_rows(reloc_ctx *ctx) { return ctx ? ctx->db_rows : -1
 RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, const int32_t *n_cur_dev, int n_cur_max,
                                         int32_t *counts_dev)
 {
-    ARG_CHECK(ctx && cur_dev && counts_dev && n_cur_max >= 0, "reloc_db_match_counts_dev");
+    ARG_CHECK_CTX(ctx, cur_dev && counts_dev && n_cur_max >= 0, "reloc_db_match_counts_dev");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     int rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, cur_dev,
@@ -820,7 +820,7 @@ RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, 
 
 RELOC_API int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, double ratio, int32_t *counts)
 {
-    ARG_CHECK(ctx && counts && n_cur >= 0 && (n_cur == 0 || cur) && ratio > 0, "reloc_db_ratio_counts");
+    ARG_CHECK_CTX(ctx, counts && n_cur >= 0 && (n_cur == 0 || cur) && ratio > 0, "reloc_db_ratio_counts");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
     if (n_cur > 65535) { reloc_set_error("ratio scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
@@ -840,7 +840,7 @@ RELOC_API int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cu
 
 RELOC_API int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts)
 {
-    ARG_CHECK(ctx && counts && n_cur >= 0 && (n_cur == 0 || cur), "reloc_db_match_counts");
+    ARG_CHECK_CTX(ctx, counts && n_cur >= 0 && (n_cur == 0 || cur), "reloc_db_match_counts");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
     void *dc;

@@ -761,7 +761,7 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
 // ------------------------------------------------------------------------------------------------
 RELOC_API int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, int stride, int order, uint8_t *gray)
 {
-    ARG_CHECK(ctx && img && gray && w > 0 && h > 0 && stride >= 3 * w, "reloc_gray_u8");
+    ARG_CHECK_CTX(ctx, img && gray && w > 0 && h > 0 && stride >= 3 * w, "reloc_gray_u8");
     if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
     void *dout;
     int rc;
@@ -777,7 +777,7 @@ RELOC_API int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, in
 
 RELOC_API int reloc_orb_frame_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int stride, int order, int nfeatures)
 {
-    ARG_CHECK(ctx && img_dev && w >= 64 && h >= 64 && stride >= 3 * w && nfeatures > 0, "reloc_orb_frame_dev");
+    ARG_CHECK_CTX(ctx, img_dev && w >= 64 && h >= 64 && stride >= 3 * w && nfeatures > 0, "reloc_orb_frame_dev");
     return orb_run_dev(ctx, img_dev, w, h, stride, 3, order, nfeatures);
 }
 
@@ -789,7 +789,7 @@ RELOC_API int reloc_orb_detect_compute(reloc_ctx *ctx, const uint8_t *gray, int 
                                        float *xy, float *size, float *angle, float *response, int32_t *octave,
                                        uint8_t *desc, int32_t *n_out)
 {
-    ARG_CHECK(ctx && gray && n_out && w > 0 && h > 0 && stride >= w && nfeatures > 0, "reloc_orb_detect_compute");
+    ARG_CHECK_CTX(ctx, gray && n_out && w > 0 && h > 0 && stride >= w && nfeatures > 0, "reloc_orb_detect_compute");
     *n_out = 0;
     if (w < 63 || h < 63) return RELOC_OK;   // no level is wider than the 31-pixel edge margin on both sides
     if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
@@ -814,7 +814,7 @@ RELOC_API int reloc_orb_detect_compute(reloc_ctx *ctx, const uint8_t *gray, int 
 
 RELOC_API int reloc_frame_debug_plane(reloc_ctx *ctx, int what, int level, uint8_t *out, int32_t *w, int32_t *h)
 {
-    ARG_CHECK(ctx && out && w && h && what >= 0 && what <= 2 && level >= 0 && level < NLEV, "reloc_frame_debug_plane");
+    ARG_CHECK_CTX(ctx, out && w && h && what >= 0 && what <= 2 && level >= 0 && level < NLEV, "reloc_frame_debug_plane");
     if (!ctx->orb_w) { reloc_set_error("no frame processed yet"); return RELOC_E_STATE; }
     const OrbLevel &L = ctx->lev[level];
     const uint8_t *src = (what == 0 ? ctx->pyr : what == 1 ? ctx->blur : ctx->nms) + L.off;

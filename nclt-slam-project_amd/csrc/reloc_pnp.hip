@@ -570,7 +570,7 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
 RELOC_API int reloc_pnp_score(reloc_ctx *ctx, const float *obj, const float *img, int m, const double *Rt, int H,
                               const double K4[4], float thr_px, int32_t *inlier_count, uint8_t *mask)
 {
-    ARG_CHECK(ctx && m >= 0 && H >= 0 && K4 && (H == 0 || (Rt && inlier_count)) && (m == 0 || (obj && img)),
+    ARG_CHECK_CTX(ctx, m >= 0 && H >= 0 && K4 && (H == 0 || (Rt && inlier_count)) && (m == 0 || (obj && img)),
               "reloc_pnp_score");
     if (H == 0) return RELOC_OK;
     if (m == 0) { for (int h = 0; h < H; ++h) inlier_count[h] = 0; return RELOC_OK; }
@@ -603,7 +603,7 @@ RELOC_API int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *im
                                float thr_px, double conf, uint64_t seed, double rvec[3], double tvec[3],
                                int32_t *inliers, int32_t *n_inl, int32_t *ok)
 {
-    ARG_CHECK(ctx && m >= 0 && K4 && rvec && tvec && n_inl && ok && (m == 0 || (obj && img && inliers)),
+    ARG_CHECK_CTX(ctx, m >= 0 && K4 && rvec && tvec && n_inl && ok && (m == 0 || (obj && img && inliers)),
               "reloc_pnp_ransac");
     ARG_CHECK(iters >= 1 && iters <= MAX_HYP, "iterationsCount must be in [1, 256]");
     *ok = 0;

@@ -107,7 +107,7 @@ RELOC_API int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint1
                                  int nfeatures, float *xy, uint8_t *desc, float *pts3d, int32_t *kp_index, int32_t *n_out,
                                  int32_t *n_kp)
 {
-    ARG_CHECK(ctx && img && depth_mm && n_out && w >= 64 && h >= 64 && nfeatures > 0, "reloc_record_frame");
+    ARG_CHECK_CTX(ctx, img && depth_mm && n_out && w >= 64 && h >= 64 && nfeatures > 0, "reloc_record_frame");
     if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
     *n_out = 0;
     if (n_kp) *n_kp = 0;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void k_depth_points(const void *__restrict__ 
 RELOC_API int reloc_depth_points(reloc_ctx *ctx, const void *depth, int is_f32, int w, int h, int step, const double K4[4],
                                  float zmin, float zmax, float *points, int32_t *n_out)
 {
-    ARG_CHECK(ctx && depth && points && n_out && w > 0 && h > 0 && step > 0 && K4, "reloc_depth_points");
+    ARG_CHECK_CTX(ctx, depth && points && n_out && w > 0 && h > 0 && step > 0 && K4, "reloc_depth_points");
     if ((int64_t)w * h > (int64_t)ctx->max_w * ctx->max_h) { reloc_set_error("depth image exceeds ctx capacity"); return RELOC_E_CAPACITY; }
     const int64_t npt = (int64_t)((w + step - 1) / step) * ((h + step - 1) / step);
     void *ddepth, *dout;

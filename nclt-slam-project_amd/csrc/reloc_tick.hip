@@ -338,7 +338,7 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
 
 RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double base_to_cam_t[3], const double base_to_cam_R[9])
 {
-    ARG_CHECK(ctx, "ctx is NULL");
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
     if (K4) for (int k = 0; k < 4; ++k) ctx->K4[k] = K4[k];
     if (base_to_cam_t) for (int k = 0; k < 3; ++k) ctx->b2c_t[k] = base_to_cam_t[k];
     if (base_to_cam_R) for (int k = 0; k < 9; ++k) ctx->b2c_R[k] = base_to_cam_R[k];
@@ -348,7 +348,7 @@ RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double 
 RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                              int global_reloc, uint64_t seed)
 {
-    ARG_CHECK(ctx && img_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_dev");
+    ARG_CHECK_CTX(ctx, img_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_dev");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (ctx->max_feat > 65535) { reloc_set_error("tick: max_feat must be <= 65535"); return RELOC_E_CAPACITY; }
     int rc;
@@ -376,7 +376,7 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
 RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj, int32_t *lm_idx,
                                 int32_t *outcome, int32_t *n_candidates)
 {
-    ARG_CHECK(ctx, "ctx is NULL");
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
     TickResult r;
     HIP_TRY(hipMemcpyAsync(&r, ctx->tick_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -393,7 +393,7 @@ RELOC_API int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int o
                          int global_reloc, uint64_t seed, double anchor_pose[7], int32_t *n_inl, float *reproj,
                          int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates)
 {
-    ARG_CHECK(ctx && img && base_pose && w >= 64 && h >= 64, "reloc_tick");
+    ARG_CHECK_CTX(ctx, img && base_pose && w >= 64 && h >= 64, "reloc_tick");
     if (w > ctx->max_w || h > ctx->max_h) { reloc_set_error("frame exceeds ctx capacity"); return RELOC_E_CAPACITY; }
     HIP_TRY(hipMemcpyAsync(ctx->frame_img, img, (size_t)w * h * 3, hipMemcpyHostToDevice, ctx->stream));
     int rc = reloc_tick_dev(ctx, ctx->frame_img, w, h, order, base_pose, global_reloc, seed);
@@ -405,7 +405,7 @@ RELOC_API int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int o
 RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                                   int32_t *topk_ids_dev, int32_t *topk_counts_dev, int k)
 {
-    ARG_CHECK(ctx && img_dev && topk_ids_dev && topk_counts_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64,
+    ARG_CHECK_CTX(ctx, img_dev && topk_ids_dev && topk_counts_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64,
               "reloc_tick_scan_dev");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
@@ -444,7 +444,7 @@ __global__ void k_set_candidates(const int32_t *__restrict__ ids, int n, int32_t
 RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand, const double base_pose[7],
                                    int check_consistency, uint64_t seed)
 {
-    ARG_CHECK(ctx && cand_ids_dev && base_pose && n_cand >= 0 && n_cand <= MAX_CAND, "reloc_tick_solve_dev");
+    ARG_CHECK_CTX(ctx, cand_ids_dev && base_pose && n_cand >= 0 && n_cand <= MAX_CAND, "reloc_tick_solve_dev");
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     hipLaunchKernelGGL(k_set_candidates, dim3(1), dim3(64), 0, ctx->stream, cand_ids_dev, n_cand, ctx->cand_ids, ctx->cand_n);
     const TickParams prm = make_tick_params(ctx, base_pose, !check_consistency, check_consistency);
@@ -455,7 +455,7 @@ RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, 
 RELOC_API int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches, int32_t *n_inl,
                                int32_t *ok, double *reproj, double *Rt)
 {
-    ARG_CHECK(ctx && cand_ids && n_cand, "reloc_tick_debug");
+    ARG_CHECK_CTX(ctx, cand_ids && n_cand, "reloc_tick_debug");
     PnpOut po[MAX_CAND];
     HIP_TRY(hipMemcpyAsync(n_cand, ctx->cand_n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(cand_ids, ctx->cand_ids, sizeof(int32_t) * MAX_CAND, hipMemcpyDeviceToHost, ctx->stream));
