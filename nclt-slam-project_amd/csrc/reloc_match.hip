@@ -81,6 +81,16 @@ __device__ __forceinline__ void ham8x2(const u32 q0[8], const u32 q1[8], const u
     d1 = acc1;
 }
 
+// ---- scalar-cache row prefetch ------------------------------------------------------------------
+// A teach row (32 B, wave-uniform address) arrives through the scalar cache.  Left alone, the compiler
+// places each scalar load directly in front of its first use, which stalls the wave for the whole
+// scalar-cache latency once per row.  scan_chunk instead issues the fetch of row t+1 between "row t has
+// landed" and "row t is used": srow_landed() is an empty asm that reads one dword of row t, so the
+// compiler's own waitcnt bookkeeping puts the wait for row t there (scalar loads return out of order:
+// any wait is a wait for all of them, hence exactly one fetch in flight), and sched barriers keep the
+// next fetch above the ~180 VALU instructions that hide its latency.
+__device__ __forceinline__ void srow_landed(u32 first_dword) { asm volatile("" ::"s"(first_dword)); }
+
 __device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u32 umax(u32 a, u32 b) { return a > b ? a : b; }
 
@@ -142,32 +152,30 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
     u32 rk[R];
+    // Teach rows come through the scalar cache, one fetch in flight (see srow_landed).
+    auto row_of = [&](int t) { return CLAMP ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
+    uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
 #pragma unroll
-    for (int t = 0; t < R; t += 2) {
-        int r[2];
-        uint4 a[2], b[2];
+    for (int t = 0; t < R; ++t) {
+        srow_landed(a.x);                                                // row t is here ...
+        uint4 na, nb;
+        if (t + 1 < R) { na = rec[2 * row_of(t + 1)]; nb = rec[2 * row_of(t + 1) + 1]; }   // ... row t+1 on its way
+        __builtin_amdgcn_sched_barrier(0);
+        u32 best = 0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            r[e] = CLAMP ? min(tc + t + e, n - 1) : tc + t + e;   // wave-uniform -> scalar loads
-            a[e] = rec[2 * r[e]];
-            b[e] = rec[2 * r[e] + 1];
+        for (int j = 0; j < NJ; j += 2) {
+            u32 h0, h1;
+            ham8x2(q[j], q[j + 1], a, b, bias[j], bias[j + 1], h0, h1);
+            const u32 kd0 = shl4_u16(h0), kd1 = shl4_u16(h1);          // (d << 4), 16 bit
+            cb16[j] = min_u16(cb16[j], kd0 | (u32)t);                  // best row of column j
+            cb16[j + 1] = min_u16(cb16[j + 1], kd1 | (u32)t);
+            const u32 rk0 = kd0 | (u32)j, rk1 = kd1 | (u32)(j + 1);    // best column of this row
+            best = j == 0 ? min_u16(rk0, rk1) : min_u16(best, min_u16(rk0, rk1));
         }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            u32 best = 0;
-#pragma unroll
-            for (int j = 0; j < NJ; j += 2) {
-                u32 h0, h1;
-                ham8x2(q[j], q[j + 1], a[e], b[e], bias[j], bias[j + 1], h0, h1);
-                const u32 kd0 = shl4_u16(h0), kd1 = shl4_u16(h1);          // (d << 4), 16 bit
-                cb16[j] = min_u16(cb16[j], kd0 | (u32)(t + e));            // best row of column j
-                cb16[j + 1] = min_u16(cb16[j + 1], kd1 | (u32)(t + e));
-                const u32 rk0 = kd0 | (u32)j, rk1 = kd1 | (u32)(j + 1);    // best column of this row
-                best = j == 0 ? min_u16(rk0, rk1) : min_u16(best, min_u16(rk0, rk1));
-            }
-            // 32-bit cross-lane key: distance << 16 | column
-            rk[t + e] = ((best >> 4) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
-        }
+        // 32-bit cross-lane key: distance << 16 | column
+        rk[t] = ((best >> 4) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < R) { a = na; b = nb; }
     }
     const u32 m = rows_min<R>(rk, lane);
     const int row = tc + (lane & (R - 1));
@@ -409,7 +417,12 @@ static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64
     int per_cu = NJ == 4 ? 8 : 4;
     const int lds_limit = (int)((160 * 1024) / (lds > 0 ? lds : 1));
     if (per_cu > lds_limit) per_cu = lds_limit > 0 ? lds_limit : 1;
-    int grid = ctx->num_cu * per_cu;
+    // 2.5 generations of resident workgroups: measured best on MI355X for both the stand-alone scan
+    // (finer load balance than one resident generation, 192 -> 183 us) and for several contexts sharing
+    // the chip (slots turn over, other streams' kernels get in); beyond ~12 per CU the per-workgroup
+    // prologue (reload of the 500 current descriptors) costs more than the balance gains.
+    int grid = ctx->num_cu * (NJ == 8 ? 10 : per_cu);
+    if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // dev switch
     if (grid > n_ids_max) grid = n_ids_max;
     const bool emit = m_qidx != nullptr;
     if (emit)
@@ -502,20 +515,6 @@ __global__ void k_knn2_merge(const u32 *__restrict__ part, int na, int nsplit, i
 constexpr int MAT_ROWS = 128;      // row tile of the unaligned fallback kernel
 constexpr int MAT_UNIT_ROWS = 8;   // rows per work unit of the persistent kernel
 
-struct MatRows { uint4 a[4], b[4]; };   // four A rows (wave-uniform: lives in SGPRs)
-
-__device__ __forceinline__ MatRows mat_load(const uint4 *__restrict__ A, int64_t i, int64_t last)
-{
-    MatRows r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int64_t ii = i + e < last ? i + e : last;
-        r.a[e] = A[2 * ii];
-        r.b[e] = A[2 * ii + 1];
-    }
-    return r;
-}
-
 // Persistent: the grid is sized to what is resident at once (a grid a few percent larger than that
 // runs a second, almost empty round and loses ~30 %).  A workgroup is bound to one column tile
 // (blockIdx % n_col_tiles) so its 8 x 256 B columns stay in registers, and takes the 8-row units
@@ -535,30 +534,38 @@ __device__ __forceinline__ void matrix_body(const uint4 *__restrict__ A, int64_t
         b[c][4] = hi.x; b[c][5] = hi.y; b[c][6] = hi.z; b[c][7] = hi.w;
     }
     if (!FULL && j0 >= nb) return;
+    // A rows come through the scalar cache, one fetch in flight: the fetch of the next row (of this unit,
+    // or the first row of this workgroup's next unit) is issued as soon as the current row has landed and
+    // hides behind the current row's ~135 VALU instructions (see srow_landed)
+    const int64_t last = na - 1;
+    auto row_at = [&](int64_t i) { return i < last ? i : last; };
+    int64_t i_first = row_at((int64_t)k0 * MAT_UNIT_ROWS);
+    uint4 ra = A[2 * i_first], rb = A[2 * i_first + 1];
     for (int unit = k0; unit < n_units; unit += kstep) {
         const int64_t i0 = (int64_t)unit * MAT_UNIT_ROWS;
-        MatRows nxt = mat_load(A, i0, na - 1);
 #pragma unroll
-        for (int g = 0; g < MAT_UNIT_ROWS; g += 4) {
-            const MatRows cur = nxt;
-            if (g + 4 < MAT_UNIT_ROWS) nxt = mat_load(A, i0 + g + 4, na - 1);
+        for (int e = 0; e < MAT_UNIT_ROWS; ++e) {
+            srow_landed(ra.x);
+            const int64_t inext = row_at(e + 1 < MAT_UNIT_ROWS ? i0 + e + 1 : i0 + (int64_t)kstep * MAT_UNIT_ROWS);
+            const uint4 na_ = A[2 * inext], nb_ = A[2 * inext + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            u32 w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32 w[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const u32 odd = ham8(b[2 * p + 1], cur.a[e], cur.b[e], 0);
-                    w[p] = ham8(b[2 * p], cur.a[e], cur.b[e], odd << 16);
-                }
-                if (i0 + g + e < na) {
-                    uint16_t *o = out + (i0 + g + e) * nb + j0;
-                    if (FULL || j0 + 8 <= nb) {
-                        *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
-                    } else {
-                        for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
-                    }
+            for (int p = 0; p < 4; ++p) {
+                const u32 odd = ham8(b[2 * p + 1], ra, rb, 0);
+                w[p] = ham8(b[2 * p], ra, rb, odd << 16);
+            }
+            if (i0 + e < na) {
+                uint16_t *o = out + (i0 + e) * nb + j0;
+                if (FULL || j0 + 8 <= nb) {
+                    *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else {
+                    for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            ra = na_;
+            rb = nb_;
         }
     }
 }
@@ -815,6 +822,7 @@ RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, 
     int rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, cur_dev,
                             n_cur_dev, n_cur_max, ctx->db_max_rows, counts_dev, nullptr, nullptr, nullptr, nullptr, 0);
     reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+
     return rc;
 }
 

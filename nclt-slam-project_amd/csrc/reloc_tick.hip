@@ -63,42 +63,82 @@ __device__ __forceinline__ void cur_heading(const TickParams &prm, double &cc, d
     sc = n > 0 ? Rb[3] / n : 0.0;
 }
 
-// Block-wide "k largest keys, descending" (keys unique, 0 = not eligible): every thread owns the
-// records i = tid, tid+1024, ... and keeps the best key it has not yet given up; per round one
-// wave-shuffle + LDS reduction finds the global maximum and only its owner rescans its few records.
+// Block-wide "k largest keys, descending" (keys unique, 0 = not eligible) without barriers in the
+// selection loops: every wave first extracts the k largest keys of ITS records (record i belongs to
+// thread i mod TICK_BLOCK) with shuffles only -- per round one wave max-reduction, and only the lane that
+// owned the maximum moves on to its next key -- then wave 0 merges the per-wave winners the
+// same way.  One __syncthreads in total.  s_part: TICK_WAVES * TOPK_MAX entries.
+// The single-block tick kernels use 256 threads (one wave per SIMD): a block of that shape fits into the
+// slot one retiring k_db_scan workgroup frees, so these kernels of one stream start while another
+// stream's scan still fills the chip; a 1024-thread block would wait for a whole CU to drain.
+constexpr int TOPK_MAX = 32;
+constexpr int TICK_BLOCK = 256, TICK_WAVES = TICK_BLOCK / 64;
+static_assert(MAX_CAND <= TOPK_MAX, "candidate slots");
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 template <typename KeyFn>
-__device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_red, unsigned long long *out_keys)
+__device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_part, unsigned long long *out_keys)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto next_below = [&](unsigned long long bound) {
-        unsigned long long best = 0;
-        for (int i = tid; i < L; i += 1024) {
-            const unsigned long long key = keyfn(i);
-            if (key < bound && key > best) best = key;
+    // every thread keeps the 4 largest of its own keys sorted in registers and rescans its records only
+    // when all four have been taken (a thread rarely owns more than a few of the block's top k)
+    unsigned long long m0, m1, m2, m3;
+    bool more;
+    auto refill = [&](unsigned long long bound) {
+        m0 = m1 = m2 = m3 = 0;
+        for (int i = tid; i < L; i += TICK_BLOCK) {
+            unsigned long long key = keyfn(i);
+            if (key >= bound) continue;
+            unsigned long long t;
+            if (key > m0) { t = m0; m0 = key; key = t; }
+            if (key > m1) { t = m1; m1 = key; key = t; }
+            if (key > m2) { t = m2; m2 = key; key = t; }
+            if (key > m3) m3 = key;
         }
-        return best;
+        more = m3 != 0;
     };
-    unsigned long long mine = next_below(~0ull);
-    int n = 0;
+    refill(~0ull);
     for (int r = 0; r < k; ++r) {
-        unsigned long long v = mine;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(v, d);
-            v = o > v ? o : v;
+        const unsigned long long top = wave_max_u64(m0);
+        if (lane == 0) s_part[wave * TOPK_MAX + r] = top;
+        if (top != 0 && m0 == top) {                                  // keys are unique: exactly one owner
+            m0 = m1; m1 = m2; m2 = m3; m3 = 0;
+            if (m0 == 0 && more) refill(top);
         }
-        if (lane == 0) s_red[wave] = v;
-        __syncthreads();
-        unsigned long long top = s_red[0];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) top = s_red[w] > top ? s_red[w] : top;
-        __syncthreads();
-        if (top == 0) break;
-        if (tid == 0) out_keys[n] = top;
-        ++n;
-        if (mine == top) mine = next_below(top);
     }
-    return n;
+    __syncthreads();
+    int n = 0;
+    if (wave == 0) {
+        // lane l owns entries l, l + 64, ... of the TICK_WAVES * k per-wave winners
+        auto next_part = [&](unsigned long long bound) {
+            unsigned long long best = 0;
+            for (int e = lane; e < TICK_WAVES * k; e += 64) {
+                const unsigned long long key = s_part[(e / k) * TOPK_MAX + (e % k)];
+                if (key < bound && key > best) best = key;
+            }
+            return best;
+        };
+        unsigned long long mp = next_part(~0ull);
+        for (int r = 0; r < k; ++r) {
+            const unsigned long long top = wave_max_u64(mp);
+            if (top == 0) break;
+            if (lane == 0) out_keys[n] = top;
+            ++n;
+            if (mp == top) mp = next_part(top);
+        }
+        if (lane == 0) out_keys[TOPK_MAX] = (unsigned long long)n;
+    }
+    __syncthreads();
+    return (int)out_keys[TOPK_MAX];
 }
 
 // ---- candidate selection, local mode (M:293-302) --------------------------------------------------
@@ -106,11 +146,11 @@ __device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_red, 
 // Order key: the bit pattern of a non-negative double is monotone in its value; the top 44 bits of it
 // order the candidates (ties at that resolution, < 1e-9 relative, fall back to the lower index), the
 // radius test itself uses the exact distance.
-__global__ __launch_bounds__(1024) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
+__global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
                                                            int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
 {
-    __shared__ unsigned long long s_red[16];
-    __shared__ unsigned long long s_keys[RELOC_MAX_CANDIDATES * 3];
+    __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
+    __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int L = prm.n_records;
     const double vx = prm.base_pose[0], vy = prm.base_pose[1];
     auto keyfn = [&](int i) -> unsigned long long {
@@ -138,12 +178,12 @@ __global__ __launch_bounds__(1024) void k_candidates_local(const double *__restr
 // ---- candidate selection, global mode (G:329-344) -------------------------------------------------
 // top-k of (count, id) descending among heading-compatible records with count >= MIN_MATCHES.
 // xyh == NULL skips the heading mask (plain top-k of the counts: sharded scan).
-__global__ __launch_bounds__(1024) void k_topk_counts(const int32_t *__restrict__ counts, const double *__restrict__ xyh,
+__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, const double *__restrict__ xyh,
                                                       TickParams prm, int k, int id_base, int32_t *__restrict__ out_ids,
                                                       int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n)
 {
-    __shared__ unsigned long long s_red[16];
-    __shared__ unsigned long long s_keys[MAX_CAND];
+    __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
+    __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int L = prm.n_records;
     double cc = 1.0, sc = 0.0;
     if (xyh) cur_heading(prm, cc, sc);
@@ -172,10 +212,10 @@ __global__ __launch_bounds__(1024) void k_topk_counts(const int32_t *__restrict_
 // ---- heading pool (G:329-330) ---------------------------------------------------------------------
 // ids of the heading-compatible records, ascending (block-wide ordered compaction), and zeroed counts:
 // the whole-database scan then only visits records the reference would score.
-__global__ __launch_bounds__(1024) void k_heading_pool(const double *__restrict__ xyh, TickParams prm, int32_t *__restrict__ ids,
+__global__ __launch_bounds__(TICK_BLOCK) void k_heading_pool(const double *__restrict__ xyh, TickParams prm, int32_t *__restrict__ ids,
                                                        int32_t *__restrict__ n_out, int32_t *__restrict__ counts)
 {
-    __shared__ int s_wsum[16];
+    __shared__ int s_wsum[TICK_WAVES];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = prm.n_records;
@@ -184,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_heading_pool(const double *__restrict_
     const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < L; i0 += 1024) {
+    for (int i0 = 0; i0 < L; i0 += TICK_BLOCK) {
         const int i = i0 + tid;
         bool keep = false;
         if (i < L) {
@@ -197,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_heading_pool(const double *__restrict_
         int before = s_base;
         for (int w = 0; w < wave; ++w) before += s_wsum[w];
         int total = 0;
-        for (int w = 0; w < 16; ++w) total += s_wsum[w];
+        for (int w = 0; w < TICK_WAVES; ++w) total += s_wsum[w];
         if (keep) ids[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
         if (tid == 0) s_base += total;
@@ -357,7 +397,7 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
     hipStream_t st = ctx->stream;
     if (global_reloc) {
         // G:329-344: only heading-compatible records are scored
-        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(1024), 0, st, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
+        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
                            ctx->db_counts);
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
@@ -365,10 +405,10 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
                             nullptr, 0);
         reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, st, ctx->db_counts, ctx->db_xy_heading, prm,
+        hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_counts, ctx->db_xy_heading, prm,
                            RELOC_GLOBAL_MAX_CANDIDATES, 0, ctx->cand_ids, (int32_t *)nullptr, ctx->cand_n);
     } else {
-        hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(1024), 0, st, ctx->db_xy_heading, prm, ctx->cand_ids, ctx->cand_n);
+        hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_xy_heading, prm, ctx->cand_ids, ctx->cand_n);
     }
     return tick_solve(ctx, prm, seed);
 }
@@ -413,7 +453,7 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
     const TickParams prm = make_tick_params(ctx, base_pose ? base_pose : zero_pose, 1, 0);
     if (base_pose) {
-        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
+        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
                            ctx->db_counts);
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
@@ -424,7 +464,7 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     } else if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) {
         return rc;
     }
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->db_counts,
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts,
                        base_pose ? (const double *)ctx->db_xy_heading : (const double *)nullptr, prm, k, 0, topk_ids_dev,
                        topk_counts_dev, ctx->cand_n);
     HIP_TRY(hipGetLastError());
