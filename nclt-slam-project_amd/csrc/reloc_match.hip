@@ -42,10 +42,10 @@ __device__ __forceinline__ u32 min_u16(u32 a, u32 b)
     asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ u32 shl4_u16(u32 a)
+__device__ __forceinline__ u32 shl7_u16(u32 a)
 {
     u32 r;
-    asm("v_lshlrev_b16 %0, 4, %1" : "=v"(r) : "v"(a));
+    asm("v_lshlrev_b16 %0, 7, %1" : "=v"(r) : "v"(a));
     return r;
 }
 
@@ -137,16 +137,18 @@ __device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
 }
 
 constexpr int SCAN_CHUNK = 16;             // largest chunk (4-bit row index inside the 16-bit key)
-constexpr u32 KEY_INVALID_BIAS = 512u;     // added to the distance of padding columns (> 256)
 
 // One R-row chunk (R = 16 or 4) of a record against the wave's 64*NJ columns.
-//   q[j]    : descriptor of column colbase + j*64 + lane; bias[j] = 0 or KEY_INVALID_BIAS
-//   CLAMP   : tail chunk, row indices clamped to the record's last row (a duplicate row offers
-//             the same distance with a larger index, so it never wins a minimum)
+//   q[j]    : descriptor of column colbase + j*64 + lane (padding columns repeat the last real column:
+//             a duplicate offers the same distance with a larger index, so it never wins a minimum)
+//   CLAMP   : tail chunk, row indices clamped to the record's last row (same argument)
+// One 16-bit key per pair serves both directions: distance << 7 | row-in-chunk << 3 | column slot.
+// Among the rows of one column the slot bits are equal, so the minimum is (distance, row); among the
+// columns of one row the row bits are equal, so the minimum is (distance, slot).  Per pair that is
+// shift + or + 2 min on top of the 16 instructions of the distance.
 template <int NJ, int R, bool CLAMP>
 __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[NJ][8],
-                                           const u32 (&bias)[NJ], u32 colbase, u32 *rowkey, u32 *colbest,
-                                           bool single_cb, int lane)
+                                           u32 colbase, u32 *rowkey, u32 *colbest, bool single_cb, int lane)
 {
     u32 cb16[NJ];
 #pragma unroll
@@ -165,15 +167,14 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 #pragma unroll
         for (int j = 0; j < NJ; j += 2) {
             u32 h0, h1;
-            ham8x2(q[j], q[j + 1], a, b, bias[j], bias[j + 1], h0, h1);
-            const u32 kd0 = shl4_u16(h0), kd1 = shl4_u16(h1);          // (d << 4), 16 bit
-            cb16[j] = min_u16(cb16[j], kd0 | (u32)t);                  // best row of column j
-            cb16[j + 1] = min_u16(cb16[j + 1], kd1 | (u32)t);
-            const u32 rk0 = kd0 | (u32)j, rk1 = kd1 | (u32)(j + 1);    // best column of this row
-            best = j == 0 ? min_u16(rk0, rk1) : min_u16(best, min_u16(rk0, rk1));
+            ham8x2(q[j], q[j + 1], a, b, 0, 0, h0, h1);
+            const u32 k0 = shl7_u16(h0) | (u32)(t * 8 + j), k1 = shl7_u16(h1) | (u32)(t * 8 + j + 1);
+            cb16[j] = min_u16(cb16[j], k0);                            // best row of column j
+            cb16[j + 1] = min_u16(cb16[j + 1], k1);
+            best = j == 0 ? min_u16(k0, k1) : min_u16(best, min_u16(k0, k1));   // best column of this row
         }
         // 32-bit cross-lane key: distance << 16 | column
-        rk[t] = ((best >> 4) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
+        rk[t] = ((best >> 7) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < R) { a = na; b = nb; }
     }
@@ -185,7 +186,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const u32 key = ((cb16[j] >> 4) << 16) | (u32)(tc + (int)(cb16[j] & 15u));
+        const u32 key = ((cb16[j] >> 7) << 16) | (u32)(tc + (int)((cb16[j] >> 3) & 15u));
         atomicMin(&colbest[colbase + j * 64 + lane], key);
     }
 }
@@ -216,21 +217,14 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
     u32 *rowkey = colbest + ncb * CB;     // max_rows : best (distance << 16 | column) per row
     u32 *wsum = rowkey + max_rows;        // 16
 
-    u32 q[NJ][8], bias[NJ];
+    u32 q[NJ][8];
     auto load_q = [&](int colbase) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = colbase + j * 64 + lane;
-            if (col < C) {
-                const uint4 a = cur[2 * col], b = cur[2 * col + 1];
-                q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
-                q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
-                bias[j] = 0;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) q[j][k] = 0;
-                bias[j] = KEY_INVALID_BIAS;
-            }
+            const int col = min(colbase + j * 64 + lane, max(C - 1, 0));   // padding repeats the last column
+            const uint4 a = cur[2 * col], b = cur[2 * col + 1];
+            q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+            q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
         }
     };
     const bool bound = (4 % ncb) == 0;            // ncb in {1, 2, 4}: static wave -> column block binding
@@ -255,16 +249,16 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
                 if (n16 % chunk_step == 0) {
                     for (int tc = chunk0 * 16; tc < n; tc += chunk_step * 16) {
                         if (tc + 16 <= n)
-                            scan_chunk<NJ, 16, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                            scan_chunk<NJ, 16, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                         else
-                            scan_chunk<NJ, 16, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                            scan_chunk<NJ, 16, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                     }
                 } else {
                     for (int tc = chunk0 * 4; tc < n; tc += chunk_step * 4) {
                         if (tc + 4 <= n)
-                            scan_chunk<NJ, 4, false>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                            scan_chunk<NJ, 4, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                         else
-                            scan_chunk<NJ, 4, true>(rec, n, tc, q, bias, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                            scan_chunk<NJ, 4, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                     }
                 }
             }
