@@ -97,10 +97,10 @@ def cpu_baseline(frames, db, sample_records):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r1/summary.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r1e/summary.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, handled as MI355X_MICROARCH.md's HBM section prescribes); None if absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1", "summary.json")))[kernel]
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1e", "summary.json")))[kernel]
     except (OSError, KeyError, ValueError):
         return None
     # streaming 16-B/lane pattern (matrix kernel): FETCH_SIZE is doubled, WRITE_SIZE exact; the scan kernel reads through
@@ -283,8 +283,8 @@ def main():
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
                                   frac=pairs / scan_s / valu_peak_pairs,
                                   basis="measured chip ceiling of 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair "
-                                        "(tools/ubench_chain.hip); the kernel issues 22.4 VALU instructions per pair-row instead of 16 "
-                                        "(argmin bookkeeping) at 4 waves/SIMD"))
+                                        "(tools/ubench_chain.hip); the kernel issues 21.1 VALU instructions per pair instead of 16 "
+                                        "(argmin bookkeeping) and runs 4 waves/SIMD, where the same ubench tops out at 2.3e12"))
         stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan=scan_s * 1e6, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
         roofline_matrix = None
         if not args.no_matrix:

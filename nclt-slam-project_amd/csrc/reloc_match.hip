@@ -345,28 +345,28 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { k0[j] = 0xFFFFu; k1[j] = 0xFFFFu; }
                 for (int t0 = wave * 8; t0 < n; t0 += 32) {
+                    // rows through the scalar cache, one fetch in flight (see srow_landed); rows past the end
+                    // re-read the last row and are skipped below, so a duplicate never counts twice
+                    auto row_of = [&](int t) { return min(t0 + t, n - 1); };
+                    uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
 #pragma unroll
-                    for (int t = 0; t < 8; t += 2) {
-                        uint4 a[2], b[2];
+                    for (int t = 0; t < 8; ++t) {
+                        srow_landed(a.x);
+                        uint4 na, nb;
+                        if (t + 1 < 8) { na = rec[2 * row_of(t + 1)]; nb = rec[2 * row_of(t + 1) + 1]; }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t0 + t < n) {                                // wave-uniform
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int rr = min(t0 + t + e, n - 1);      // a duplicate of the last row must not count twice:
-                            a[e] = rec[2 * rr];                          // handled below by skipping rows >= n
-                            b[e] = rec[2 * rr + 1];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            if (t0 + t + e < n) {                        // wave-uniform
-#pragma unroll
-                                for (int j = 0; j < 8; j += 2) {
-                                    u32 h0, h1;
-                                    ham8x2(q[j], q[j + 1], a[e], b[e], 0, 0, h0, h1);
-                                    const u32 m0 = max_u16(k0[j], h0), m1 = max_u16(k0[j + 1], h1);
-                                    k0[j] = min_u16(k0[j], h0); k0[j + 1] = min_u16(k0[j + 1], h1);
-                                    k1[j] = min_u16(k1[j], m0); k1[j + 1] = min_u16(k1[j + 1], m1);
-                                }
+                            for (int j = 0; j < 8; j += 2) {
+                                u32 h0, h1;
+                                ham8x2(q[j], q[j + 1], a, b, 0, 0, h0, h1);
+                                const u32 m0 = max_u16(k0[j], h0), m1 = max_u16(k0[j + 1], h1);
+                                k0[j] = min_u16(k0[j], h0); k0[j + 1] = min_u16(k0[j + 1], h1);
+                                k1[j] = min_u16(k1[j], m0); k1[j + 1] = min_u16(k1[j + 1], m1);
                             }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t + 1 < 8) { a = na; b = nb; }
                     }
                 }
 #pragma unroll
