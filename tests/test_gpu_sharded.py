@@ -33,3 +33,36 @@ def test_scan_solve_equals_fused_tick(engine, oracle):
     if fused["outcome"] in (0, 4):
         assert r["n_inliers"] == fused["n_inliers"] and r["lm_idx"] == fused["lm_idx"]
         np.testing.assert_allclose(r["anchor_pose"], fused["anchor_pose"], atol=1e-9)
+
+
+def test_topk_when_one_thread_owns_most_winners(engine, oracle):
+    """k_topk_counts deals record i to thread i mod 256 and every thread keeps its four best in registers;
+    25 winners that all fall on ONE thread force the refill path (rescan below the last key taken)."""
+    rng = np.random.default_rng(77)
+    img = synth.textured_frame(rng, 640, 480)
+    feat = engine.orb_detect_compute(engine.gray(img), 500)
+    L = 256 * 26 + 8
+    winners = tuple(7 + 256 * i for i in range(25))
+    # winners: 32 rows that are noisy copies of current descriptors; everyone else: 8 random rows, which cannot
+    # reach MIN_MATCHES = 10 mutual matches, so the top list is exactly the winners
+    n = np.full(L, 8, np.int64)
+    n[list(winners)] = 32
+    off = np.zeros(L + 1, np.int64)
+    off[1:] = np.cumsum(n)
+    T = int(off[-1])
+    desc = synth.random_descriptors(rng, T)
+    for r in winners:
+        src = rng.choice(len(feat["desc"]), 32, replace=False)
+        desc[off[r]:off[r] + 32] = synth.perturb_descriptors(rng, feat["desc"][src], 0.04)
+    pts = np.zeros((T, 3), np.float32)
+    poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1))
+    engine.db_upload(desc, pts, off, poses)
+    frame_dev = engine.to_device(img)
+    ids, cnt = engine.tick_scan(frame_dev, 640, 480, None, k=25)
+    engine.dev_free(frame_dev)
+    counts = oracle.db_match_counts(desc, off, feat["desc"])
+    exp = oracle.topk_records(counts, 10, 25)
+    assert sorted(exp.tolist()) == sorted(winners)                # all 25 on thread 7 of the block
+    np.testing.assert_array_equal(ids[: len(exp)], exp)
+    np.testing.assert_array_equal(cnt[: len(exp)], counts[exp])
+    assert (ids[len(exp):] == -1).all()
