@@ -124,7 +124,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
                     c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
                     c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_off,
-                    c->db_pose, c->db_xy_heading, c->db_counts, c->pool_ids, c->pool_n, c->cand_ids, c->cand_n, c->m_qidx,
+                    c->db_pose, c->db_xy_heading, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,
                     c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
                     c->p_out, c->tick_res};
     for (void *p : ptrs)

@@ -77,6 +77,39 @@ struct PnpOut {
     int32_t n_matches;
 };
 
+// ---- heading test shared by the scan and the candidate kernels (M:296-301, G:329-330) --------------
+__device__ __forceinline__ void quat_to_rot(double qx, double qy, double qz, double qw, double R[9])
+{
+    R[0] = 1 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qz * qw);     R[2] = 2 * (qx * qz + qy * qw);
+    R[3] = 2 * (qx * qy + qz * qw);     R[4] = 1 - 2 * (qx * qx + qz * qz); R[5] = 2 * (qy * qz - qx * qw);
+    R[6] = 2 * (qx * qz - qy * qw);     R[7] = 2 * (qy * qz + qx * qw);     R[8] = 1 - 2 * (qx * qx + qy * qy);
+}
+
+// |wrap(teach_hdg - cur_hdg)| < tol  <=>  cos(teach_hdg - cur_hdg) > cos(tol); the database index keeps
+// (cos, sin) of every record's heading, so the test is one dot product.
+__device__ __forceinline__ bool heading_ok(const double *__restrict__ rec4, double cc, double sc, double cos_tol)
+{
+    return rec4[2] * cc + rec4[3] * sc > cos_tol;
+}
+__device__ __forceinline__ double heading_cos_tol() { return cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0); }
+
+// (cos, sin) of the robot's heading from the base_link quaternion (x, y, z, w)
+__device__ __forceinline__ void cur_heading_q(const double q[4], double &cc, double &sc)
+{
+    double Rb[9];
+    quat_to_rot(q[0], q[1], q[2], q[3], Rb);
+    const double n = sqrt(Rb[0] * Rb[0] + Rb[3] * Rb[3]);       // fwd = (R00, R10); only the direction matters
+    cc = n > 0 ? Rb[0] / n : 1.0;
+    sc = n > 0 ? Rb[3] / n : 0.0;
+}
+
+// Optional heading mask of the whole-database scan: records whose teach heading is incompatible with the
+// robot's are not scored (count 0), exactly the records the reference skips at G:329-330.  xyh == NULL: no mask.
+struct ScanMask {
+    const double *xyh;
+    double q[4];
+};
+
 struct reloc_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, max_feat = 0;
@@ -132,8 +165,8 @@ struct reloc_ctx {
     double *db_pose = nullptr;
     double *db_xy_heading = nullptr; // L x 4 (x, y, cos heading, sin heading) for candidate selection
     int32_t *db_counts = nullptr;    // L per-record mutual counts
-    int32_t *pool_ids = nullptr;     // L ids of the heading-compatible records of the current tick
-    int32_t *pool_n = nullptr;       // 1
+    unsigned long long *topk_part = nullptr;   // per-block winners of the two-stage top-k (topk_blocks x 32)
+    int topk_blocks = 0;
 
     // ---- tick state ----
     int32_t *cand_ids = nullptr;     // MAX_CAND
@@ -157,7 +190,7 @@ void reloc_prof_end(reloc_ctx *ctx, int which);
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
-                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride);
+                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask = nullptr);
 int db_reindex(reloc_ctx *ctx);
 int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures);
 int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,

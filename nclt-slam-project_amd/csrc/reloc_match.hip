@@ -136,7 +136,6 @@ __device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
     return x;
 }
 
-constexpr int SCAN_CHUNK = 16;             // largest chunk (4-bit row index inside the 16-bit key)
 
 // One R-row chunk (R = 16 or 4) of a record against the wave's 64*NJ columns.
 //   q[j]    : descriptor of column colbase + j*64 + lane (padding columns repeat the last real column:
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
     int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride)
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask)
 {
     extern __shared__ u32 lds[];
     constexpr int CB = 64 * NJ;           // columns per block
@@ -231,9 +230,19 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
     const int my_cb = bound ? wave % ncb : 0;
     const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? 4 / ncb : 4;
     if (bound) load_q(my_cb * CB);
+    double hc = 1.0, hs = 0.0, cos_tol = 0.0;
+    if (mask.xyh) {
+        cur_heading_q(mask.q, hc, hs);
+        cos_tol = heading_cos_tol();
+    }
 
     for (int it = blockIdx.x; it < n_ids; it += gridDim.x) {
         const int r = rec_ids ? rec_ids[it] : it;
+        if (mask.xyh && !heading_ok(mask.xyh + 4 * (int64_t)r, hc, hs, cos_tol)) {      // workgroup-uniform
+            if (tid == 0 && counts) counts[EMIT ? it : r] = 0;
+            if (EMIT && tid == 0 && m_n) m_n[it] = 0;
+            continue;
+        }
         const int64_t row0 = off[r];
         const int n = (int)(off[r + 1] - row0);
         const uint4 *rec = db + 2 * row0;
@@ -402,7 +411,7 @@ template <int NJ>
 static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, const int32_t *rec_ids,
                              const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur, const int32_t *n_cur_dev,
                              int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx, int32_t *m_tidx, int32_t *m_dist,
-                             int32_t *m_n, int emit_stride)
+                             int32_t *m_n, int emit_stride, const ScanMask &mask)
 {
     constexpr int CB = 64 * NJ;
     const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
@@ -422,11 +431,11 @@ static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64
     if (emit)
         hipLaunchKernelGGL((k_db_scan<NJ, true>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
                            rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
     else
         hipLaunchKernelGGL((k_db_scan<NJ, false>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
                            rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride);
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
@@ -434,9 +443,11 @@ static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
-                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride)
+                   int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask_p)
 {
     if (n_ids_max <= 0) return RELOC_OK;
+    ScanMask mask = {nullptr, {0, 0, 0, 1}};
+    if (mask_p) mask = *mask_p;
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
     if (max_rows < 1) max_rows = 1;
@@ -446,9 +457,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     }
     if (g_scan_nj == 4)
         return launch_db_scan_nj<4>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows,
-                                    counts, m_qidx, m_tidx, m_dist, m_n, emit_stride);
+                                    counts, m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
     return launch_db_scan_nj<8>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows, counts,
-                                m_qidx, m_tidx, m_dist, m_n, emit_stride);
+                                m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -777,7 +788,7 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     ARG_CHECK(n_records == 0 || poses, "poses missing");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     void **olds[] = {(void **)&ctx->db_desc, (void **)&ctx->db_pts3d, (void **)&ctx->db_off, (void **)&ctx->db_pose,
-                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts, (void **)&ctx->pool_ids, (void **)&ctx->pool_n};
+                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts, (void **)&ctx->topk_part};
     for (void **p : olds) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
     HIP_TRY(hipMalloc((void **)&ctx->db_desc, (size_t)(T > 0 ? T : 1) * 32));
     HIP_TRY(hipMalloc((void **)&ctx->db_pts3d, (size_t)(T > 0 ? T : 1) * 12));
@@ -785,8 +796,8 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     HIP_TRY(hipMalloc((void **)&ctx->db_pose, (size_t)(n_records > 0 ? n_records : 1) * 56));
     HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 32));
     HIP_TRY(hipMalloc((void **)&ctx->db_counts, (size_t)(n_records > 0 ? n_records : 1) * 4));
-    HIP_TRY(hipMalloc((void **)&ctx->pool_ids, (size_t)(n_records > 0 ? n_records : 1) * 4));
-    HIP_TRY(hipMalloc((void **)&ctx->pool_n, 16));
+    ctx->topk_blocks = (int)((n_records + 1023) / 1024 > 0 ? (n_records + 1023) / 1024 : 1);
+    HIP_TRY(hipMalloc((void **)&ctx->topk_part, (size_t)ctx->topk_blocks * 32 * sizeof(unsigned long long)));
     if (T > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_desc, desc, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->db_pts3d, pts3d, (size_t)T * 12, hipMemcpyHostToDevice, ctx->stream));

@@ -19,13 +19,6 @@ struct TickParams {
     int n_records;
 };
 
-__device__ void quat_to_rot(double qx, double qy, double qz, double qw, double R[9])
-{
-    R[0] = 1 - 2 * (qy * qy + qz * qz); R[1] = 2 * (qx * qy - qz * qw);     R[2] = 2 * (qx * qz + qy * qw);
-    R[3] = 2 * (qx * qy + qz * qw);     R[4] = 1 - 2 * (qx * qx + qz * qz); R[5] = 2 * (qy * qz - qx * qw);
-    R[6] = 2 * (qx * qz - qy * qw);     R[7] = 2 * (qy * qz + qx * qw);     R[8] = 1 - 2 * (qx * qx + qy * qy);
-}
-
 __device__ void rot_to_quat(const double R[9], double q[4])
 {
     const double tr = R[0] + R[4] + R[8];
@@ -47,25 +40,14 @@ __device__ void rot_to_quat(const double R[9], double q[4])
     q[0] = qx; q[1] = qy; q[2] = qz; q[3] = qw;
 }
 
-// |wrap(teach_hdg - cur_hdg)| < tol  <=>  cos(teach_hdg - cur_hdg) > cos(tol); the database index keeps
-// (cos, sin) of every record's heading, so the test is one dot product (M:296-301).
-__device__ __forceinline__ bool heading_ok(const double *__restrict__ rec4, double cc, double sc, double cos_tol)
-{
-    return rec4[2] * cc + rec4[3] * sc > cos_tol;
-}
-
 __device__ __forceinline__ void cur_heading(const TickParams &prm, double &cc, double &sc)
 {
-    double Rb[9];
-    quat_to_rot(prm.base_pose[3], prm.base_pose[4], prm.base_pose[5], prm.base_pose[6], Rb);
-    const double n = sqrt(Rb[0] * Rb[0] + Rb[3] * Rb[3]);       // fwd = (R00, R10); only the direction matters
-    cc = n > 0 ? Rb[0] / n : 1.0;
-    sc = n > 0 ? Rb[3] / n : 0.0;
+    cur_heading_q(prm.base_pose + 3, cc, sc);
 }
 
 // Block-wide "k largest keys, descending" (keys unique, 0 = not eligible) without barriers in the
 // selection loops: every wave first extracts the k largest keys of ITS records (record i belongs to
-// thread i mod TICK_BLOCK) with shuffles only -- per round one wave max-reduction, and only the lane that
+// thread (i - begin) mod TICK_BLOCK) with shuffles only -- per round one wave max-reduction, and only the lane that
 // owned the maximum moves on to its next key -- then wave 0 merges the per-wave winners the
 // same way.  One __syncthreads in total.  s_part: TICK_WAVES * TOPK_MAX entries.
 // The single-block tick kernels use 256 threads (one wave per SIMD): a block of that shape fits into the
@@ -86,7 +68,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 
 template <typename KeyFn>
-__device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_part, unsigned long long *out_keys)
+__device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long long *s_part, unsigned long long *out_keys)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // every thread keeps the 4 largest of its own keys sorted in registers and rescans its records only
@@ -95,7 +77,7 @@ __device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_part,
     bool more;
     auto refill = [&](unsigned long long bound) {
         m0 = m1 = m2 = m3 = 0;
-        for (int i = tid; i < L; i += TICK_BLOCK) {
+        for (int i = begin + tid; i < end; i += TICK_BLOCK) {
             unsigned long long key = keyfn(i);
             if (key >= bound) continue;
             unsigned long long t;
@@ -141,30 +123,80 @@ __device__ int block_topk(int L, int k, KeyFn keyfn, unsigned long long *s_part,
     return (int)out_keys[TOPK_MAX];
 }
 
-// ---- candidate selection, local mode (M:293-302) --------------------------------------------------
-// nearest 15 by (distance, index), then the radius / heading filter in that order, first 5 kept.
-// Order key: the bit pattern of a non-negative double is monotone in its value; the top 44 bits of it
-// order the candidates (ties at that resolution, < 1e-9 relative, fall back to the lower index), the
-// radius test itself uses the exact distance.
+// ---- candidate selection ---------------------------------------------------------------------------
+// Two stages, so that a 10k-record database is not walked by one workgroup: k_topk_part gives every
+// TOPK_SLICE records to one block, which leaves its k best keys in topk_part; k_topk_final merges the
+// blocks' lists (or, for a database of one slice, ranks the records directly) and applies the mode's
+// epilogue.  Keys are unique and 0 means "not eligible".
+//   local mode (M:293-302): nearest 15 by (distance, index), then the radius / heading filter in that
+//     order, first 5 kept.  Order key: the bit pattern of a non-negative double is monotone in its value;
+//     its top 44 bits order the candidates (ties at that resolution, < 1e-9 relative, fall back to the
+//     lower index), the radius test itself uses the exact distance.
+//   global mode (G:329-344): top-k of (count, id) descending among the records with count >= MIN_MATCHES
+//     (the scan leaves count 0 on heading-incompatible records, see ScanMask).
+constexpr int TOPK_SLICE = 1024;
+
+struct LocalKey {
+    const double *xyh;
+    double vx, vy;
+    __device__ unsigned long long operator()(int i) const
+    {
+        const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
+        const double d = sqrt(dx * dx + dy * dy);
+        const unsigned long long q = (unsigned long long)__double_as_longlong(d) >> 20;
+        return ((0xFFFFFFFFFFFull - q) << 20) | (unsigned long long)(0xFFFFF - (i & 0xFFFFF));   // nearer, then lower index
+    }
+};
+
+struct CountKey {
+    const int32_t *counts;
+    __device__ unsigned long long operator()(int i) const
+    {
+        const int c = counts[i];
+        return c < RELOC_MIN_MATCHES ? 0ull : ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
+    }
+};
+
+struct PartKey {
+    const unsigned long long *part;
+    int k;
+    __device__ unsigned long long operator()(int i) const { return part[(i / k) * TOPK_MAX + (i % k)]; }
+};
+
+template <typename KeyFn>
+__global__ __launch_bounds__(TICK_BLOCK) void k_topk_part(KeyFn keyfn, int L, int k, unsigned long long *__restrict__ part)
+{
+    __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
+    __shared__ unsigned long long s_keys[TOPK_MAX + 1];
+    const int begin = blockIdx.x * TOPK_SLICE, end = min(L, begin + TOPK_SLICE);
+    const int n = block_topk(begin, end, k, keyfn, s_red, s_keys);
+    __syncthreads();
+    if ((int)threadIdx.x < k) part[blockIdx.x * TOPK_MAX + threadIdx.x] = (int)threadIdx.x < n ? s_keys[threadIdx.x] : 0ull;
+}
+
+// n_blocks == 0: rank the L records directly; otherwise merge n_blocks lists of k keys
+template <typename KeyFn>
+__device__ int topk_final(KeyFn keyfn, int L, int k, const unsigned long long *part, int n_blocks, unsigned long long *s_red,
+                          unsigned long long *s_keys)
+{
+    if (n_blocks == 0) return block_topk(0, L, k, keyfn, s_red, s_keys);
+    return block_topk(0, n_blocks * k, k, PartKey{part, k}, s_red, s_keys);
+}
+
 __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
-                                                           int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
+                                                                 const unsigned long long *__restrict__ part, int n_blocks,
+                                                                 int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
 {
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int L = prm.n_records;
     const double vx = prm.base_pose[0], vy = prm.base_pose[1];
-    auto keyfn = [&](int i) -> unsigned long long {
-        const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
-        const double d = sqrt(dx * dx + dy * dy);
-        const unsigned long long q = (unsigned long long)__double_as_longlong(d) >> 20;
-        return ((0xFFFFFFFFFFFull - q) << 20) | (unsigned long long)(0xFFFFF - (i & 0xFFFFF));   // nearer, then lower index
-    };
-    const int n = block_topk(L, min(RELOC_MAX_CANDIDATES * 3, L), keyfn, s_red, s_keys);
+    const int n = topk_final(LocalKey{xyh, vx, vy}, L, min(RELOC_MAX_CANDIDATES * 3, L), part, n_blocks, s_red, s_keys);
     __syncthreads();
     if (threadIdx.x == 0) {
         double cc, sc;
         cur_heading(prm, cc, sc);
-        const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
+        const double cos_tol = heading_cos_tol();
         int m = 0;
         for (int r = 0; r < n && m < RELOC_MAX_CANDIDATES; ++r) {
             const int i = 0xFFFFF - (int)(s_keys[r] & 0xFFFFF);
@@ -175,26 +207,14 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *_
     }
 }
 
-// ---- candidate selection, global mode (G:329-344) -------------------------------------------------
-// top-k of (count, id) descending among heading-compatible records with count >= MIN_MATCHES.
-// xyh == NULL skips the heading mask (plain top-k of the counts: sharded scan).
-__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, const double *__restrict__ xyh,
-                                                      TickParams prm, int k, int id_base, int32_t *__restrict__ out_ids,
-                                                      int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n)
+__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base,
+                                                            const unsigned long long *__restrict__ part, int n_blocks,
+                                                            int32_t *__restrict__ out_ids, int32_t *__restrict__ out_counts,
+                                                            int32_t *__restrict__ out_n)
 {
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
-    const int L = prm.n_records;
-    double cc = 1.0, sc = 0.0;
-    if (xyh) cur_heading(prm, cc, sc);
-    const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
-    auto keyfn = [&](int i) -> unsigned long long {
-        const int c = counts[i];
-        if (c < RELOC_MIN_MATCHES) return 0ull;
-        if (xyh && !heading_ok(xyh + 4 * i, cc, sc, cos_tol)) return 0ull;
-        return ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
-    };
-    const int n = block_topk(L, k, keyfn, s_red, s_keys);
+    const int n = topk_final(CountKey{counts}, L, k, part, n_blocks, s_red, s_keys);
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < k) {
@@ -209,41 +229,27 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__res
     if (tid == 0) *out_n = n;
 }
 
-// ---- heading pool (G:329-330) ---------------------------------------------------------------------
-// ids of the heading-compatible records, ascending (block-wide ordered compaction), and zeroed counts:
-// the whole-database scan then only visits records the reference would score.
-__global__ __launch_bounds__(TICK_BLOCK) void k_heading_pool(const double *__restrict__ xyh, TickParams prm, int32_t *__restrict__ ids,
-                                                       int32_t *__restrict__ n_out, int32_t *__restrict__ counts)
+// host side of the two stages (one launch when the database is a single slice)
+static void launch_candidates_local(reloc_ctx *ctx, const TickParams &prm)
 {
-    __shared__ int s_wsum[TICK_WAVES];
-    __shared__ int s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = prm.n_records;
-    double cc, sc;
-    cur_heading(prm, cc, sc);
-    const double cos_tol = cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0);
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < L; i0 += TICK_BLOCK) {
-        const int i = i0 + tid;
-        bool keep = false;
-        if (i < L) {
-            counts[i] = 0;
-            keep = heading_ok(xyh + 4 * i, cc, sc, cos_tol);
-        }
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) s_wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int before = s_base;
-        for (int w = 0; w < wave; ++w) before += s_wsum[w];
-        int total = 0;
-        for (int w = 0; w < TICK_WAVES; ++w) total += s_wsum[w];
-        if (keep) ids[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        __syncthreads();
-        if (tid == 0) s_base += total;
-        __syncthreads();
-    }
-    if (tid == 0) *n_out = s_base;
+    const int L = prm.n_records, k = L < RELOC_MAX_CANDIDATES * 3 ? L : RELOC_MAX_CANDIDATES * 3;
+    const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
+    if (nb)
+        hipLaunchKernelGGL(k_topk_part<LocalKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream,
+                           LocalKey{ctx->db_xy_heading, prm.base_pose[0], prm.base_pose[1]}, L, k, ctx->topk_part);
+    hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->topk_part, nb,
+                       ctx->cand_ids, ctx->cand_n);
+}
+
+static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts)
+{
+    const int L = (int)ctx->db_records;
+    const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
+    if (nb)
+        hipLaunchKernelGGL(k_topk_part<CountKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream, CountKey{ctx->db_counts}, L, k,
+                           ctx->topk_part);
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, ctx->topk_part, nb,
+                       out_ids, out_counts, ctx->cand_n);
 }
 
 // ---- gather (M:333-336) ---------------------------------------------------------------------------
@@ -394,21 +400,18 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
     int rc;
     if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
     const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, !global_reloc);
-    hipStream_t st = ctx->stream;
     if (global_reloc) {
-        // G:329-344: only heading-compatible records are scored
-        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
-                           ctx->db_counts);
+        // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others)
+        ScanMask mask = {ctx->db_xy_heading, {base_pose[3], base_pose[4], base_pose[5], base_pose[6]}};
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
-        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
-                            ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr,
-                            nullptr, 0);
+        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
+                            ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
+                            &mask);
         reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_counts, ctx->db_xy_heading, prm,
-                           RELOC_GLOBAL_MAX_CANDIDATES, 0, ctx->cand_ids, (int32_t *)nullptr, ctx->cand_n);
+        launch_topk_counts(ctx, RELOC_GLOBAL_MAX_CANDIDATES, ctx->cand_ids, nullptr);
     } else {
-        hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(TICK_BLOCK), 0, st, ctx->db_xy_heading, prm, ctx->cand_ids, ctx->cand_n);
+        launch_candidates_local(ctx, prm);
     }
     return tick_solve(ctx, prm, seed);
 }
@@ -450,23 +453,14 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
     if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
-    double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
-    const TickParams prm = make_tick_params(ctx, base_pose ? base_pose : zero_pose, 1, 0);
-    if (base_pose) {
-        hipLaunchKernelGGL(k_heading_pool, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->pool_ids, ctx->pool_n,
-                           ctx->db_counts);
-        reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
-        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->pool_ids, ctx->pool_n, (int)ctx->db_records,
-                            ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr,
-                            nullptr, 0);
-        reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
-        if (rc) return rc;
-    } else if ((rc = reloc_db_match_counts_dev(ctx, ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_counts))) {
-        return rc;
-    }
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts,
-                       base_pose ? (const double *)ctx->db_xy_heading : (const double *)nullptr, prm, k, 0, topk_ids_dev,
-                       topk_counts_dev, ctx->cand_n);
+    ScanMask mask = {nullptr, {0, 0, 0, 1}};
+    if (base_pose) mask = ScanMask{ctx->db_xy_heading, {base_pose[3], base_pose[4], base_pose[5], base_pose[6]}};
+    reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
+    rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
+                        ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0, &mask);
+    reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+    if (rc) return rc;
+    launch_topk_counts(ctx, k, topk_ids_dev, topk_counts_dev);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
