@@ -252,23 +252,21 @@ __global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
         if (n > 0 && C > 0) {
             for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
                 if (!bound) load_q(cb * CB);
-                // 16-row chunks when they deal out evenly over the waves bound to this column block, 4-row
-                // chunks otherwise (a 45-row record is 3 x 16 -> one of 4 waves idle, but 12 x 4 -> 3 each)
-                const int n16 = (n + 15) >> 4;
-                if (n16 % chunk_step == 0) {
-                    for (int tc = chunk0 * 16; tc < n; tc += chunk_step * 16) {
-                        if (tc + 16 <= n)
-                            scan_chunk<NJ, 16, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                        else
-                            scan_chunk<NJ, 16, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                    }
-                } else {
-                    for (int tc = chunk0 * 4; tc < n; tc += chunk_step * 4) {
-                        if (tc + 4 <= n)
-                            scan_chunk<NJ, 4, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                        else
-                            scan_chunk<NJ, 4, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                    }
+                // The record's rows are dealt to the waves bound to this column block as contiguous ranges,
+                // balanced in units of 4 rows; a wave walks its range in 16-row chunks and finishes it in 4-row
+                // chunks (n = 64: one 16-row chunk each; n = 100: 28/24/24/24 rows instead of 32/32/32/4).  A tail
+                // chunk may run past the range: rows that belong to the next wave are simply computed twice (all
+                // merges are idempotent minima), rows past the record are clamped.
+                const int units = (n + 3) >> 2, per = units / chunk_step, extra = units % chunk_step;
+                int tc = (chunk0 * per + min(chunk0, extra)) * 4;
+                const int tend = min(n, tc + (per + (chunk0 < extra ? 1 : 0)) * 4);
+                for (; tend - tc >= 16; tc += 16)
+                    scan_chunk<NJ, 16, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                for (; tc < tend; tc += 4) {
+                    if (tc + 4 <= n)
+                        scan_chunk<NJ, 4, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+                    else
+                        scan_chunk<NJ, 4, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
                 }
             }
         }
