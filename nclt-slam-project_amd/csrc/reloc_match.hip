@@ -195,10 +195,10 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // number of column blocks ncb divides 4, wave w is bound to block w % ncb for the whole launch (its
 // descriptors stay in registers) and takes the 16-row chunks w / ncb, w / ncb + 4 / ncb, ...;
 // otherwise every wave walks all column blocks and reloads its registers per block.
-// NJ = 8: 500 descriptors are one block (64 VGPRs of descriptors, 4 waves per SIMD);
-// NJ = 4: two blocks, ~64 VGPRs in total, 8 waves per SIMD.
+// NJ = 8 (the only instantiation): 500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per
+// SIMD.  NJ = 4 (two blocks, 8 waves per SIMD) was measured slower on MI355X (188 vs 176 us) and dropped.
 template <int NJ, bool EMIT>
-__global__ __launch_bounds__(256, (NJ == 4 ? 8 : 4)) void k_db_scan(
+__global__ __launch_bounds__(256, 4) void k_db_scan(
     const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
@@ -403,40 +403,7 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
     }
 }
 
-static int g_scan_nj = 0;   // 0 = default; RELOC_SCAN_NJ=4|8 overrides (developer switch)
-
-template <int NJ>
-static int launch_db_scan_nj(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, const int32_t *rec_ids,
-                             const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur, const int32_t *n_cur_dev,
-                             int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx, int32_t *m_tidx, int32_t *m_dist,
-                             int32_t *m_n, int emit_stride, const ScanMask &mask)
-{
-    constexpr int CB = 64 * NJ;
-    const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
-    const size_t lds = (size_t)(ncb * CB + max_rows + 16) * 4;
-    if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
-    int per_cu = NJ == 4 ? 8 : 4;
-    const int lds_limit = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-    if (per_cu > lds_limit) per_cu = lds_limit > 0 ? lds_limit : 1;
-    // 2.5 generations of resident workgroups: measured best on MI355X for both the stand-alone scan
-    // (finer load balance than one resident generation, 192 -> 183 us) and for several contexts sharing
-    // the chip (slots turn over, other streams' kernels get in); beyond ~12 per CU the per-workgroup
-    // prologue (reload of the 500 current descriptors) costs more than the balance gains.
-    int grid = ctx->num_cu * (NJ == 8 ? 10 : per_cu);
-    if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // dev switch
-    if (grid > n_ids_max) grid = n_ids_max;
-    const bool emit = m_qidx != nullptr;
-    if (emit)
-        hipLaunchKernelGGL((k_db_scan<NJ, true>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
-    else
-        hipLaunchKernelGGL((k_db_scan<NJ, false>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
-    HIP_TRY(hipGetLastError());
-    return RELOC_OK;
-}
+constexpr int SCAN_NJ = 8;
 
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
@@ -449,15 +416,27 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
     if (max_rows < 1) max_rows = 1;
-    if (!g_scan_nj) {
-        const char *e = getenv("RELOC_SCAN_NJ");
-        g_scan_nj = (e && e[0] == '4') ? 4 : 8;
-    }
-    if (g_scan_nj == 4)
-        return launch_db_scan_nj<4>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows,
-                                    counts, m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
-    return launch_db_scan_nj<8>(ctx, db_desc, db_off, rec_ids, n_ids_dev, n_ids_max, cur, n_cur_dev, n_cur_max, max_rows, counts,
-                                m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
+    constexpr int CB = 64 * SCAN_NJ;
+    const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
+    const size_t lds = (size_t)(ncb * CB + max_rows + 16) * 4;
+    if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
+    // 2.5 generations of resident workgroups (4 per CU are resident): measured best on MI355X for both the
+    // stand-alone scan (finer load balance than one resident generation, 192 -> 183 us) and for several
+    // contexts sharing the chip (slots turn over, other streams' kernels get in); beyond ~12 per CU the
+    // per-workgroup prologue (reload of the 500 current descriptors) costs more than the balance gains.
+    int grid = ctx->num_cu * 10;
+    if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer switch
+    if (grid > n_ids_max) grid = n_ids_max;
+    if (m_qidx)
+        hipLaunchKernelGGL((k_db_scan<SCAN_NJ, true>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
+    else
+        hipLaunchKernelGGL((k_db_scan<SCAN_NJ, false>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
+                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
+                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
