@@ -281,20 +281,28 @@ class Engine:
         N.check(self._lib.reloc_tick_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
                                          int(global_reloc), int(seed)), "reloc_tick_dev")
 
-    def tick_scan(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
-        """ORB + whole-shard scan + local top-k; returns (local record ids (k,), counts (k,)), -1 / 0 padded."""
+    def tick_scan_enqueue(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
+        """ORB + whole-shard scan + local top-k, enqueued on the ctx stream; read with tick_scan_fetch(k)."""
         if not hasattr(self, "_topk_dev"):
             self._topk_dev = self.dev_alloc(2 * 32 * 4)
         bp = None if base_pose is None else np.ascontiguousarray(base_pose, np.float64).reshape(7)
         N.check(self._lib.reloc_tick_scan_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
                                               C.c_void_p(self._topk_dev), C.c_void_p(self._topk_dev + 128), int(k)),
                 "reloc_tick_scan_dev")
+
+    def tick_scan_fetch(self, k: int = 25):
+        """(local record ids (k,), counts (k,)) of the last enqueued scan, -1 / 0 padded (synchronises the stream)."""
         buf = np.empty(64, np.int32)
         self.d2h(buf, self._topk_dev)
         return buf[:k].copy(), buf[32:32 + k].copy()
 
-    def tick_solve(self, local_ids, base_pose, check_consistency: bool, seed: int = 0):
-        """matches + PnP + gates for the listed LOCAL record ids against the features of the last scan"""
+    def tick_scan(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
+        self.tick_scan_enqueue(img_dev, w, h, base_pose, k, order_rgb)
+        return self.tick_scan_fetch(k)
+
+    def tick_solve_enqueue(self, local_ids, base_pose, check_consistency: bool, seed: int = 0):
+        """matches + PnP + gates for the listed LOCAL record ids against the features of the last scan; read with
+        tick_result()."""
         ids = np.full(32, -1, np.int32)
         ids[: len(local_ids)] = local_ids
         if not hasattr(self, "_cand_dev"):
@@ -303,6 +311,9 @@ class Engine:
         bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
         N.check(self._lib.reloc_tick_solve_dev(self._ctx, C.c_void_p(self._cand_dev), len(local_ids), N.ptr(bp),
                                                int(check_consistency), int(seed)), "reloc_tick_solve_dev")
+
+    def tick_solve(self, local_ids, base_pose, check_consistency: bool, seed: int = 0):
+        self.tick_solve_enqueue(local_ids, base_pose, check_consistency, seed)
         return self.tick_result()
 
     def tick_result(self):

@@ -34,9 +34,12 @@ def merge_topk(all_ids, all_counts, k=K_GLOBAL):
 
 class ShardedRelocalizer:
     """backend: an object with
-         scan(frame, base_pose, k) -> (local ids (k,), counts (k,)) padded with -1 / 0
-         solve(local_ids, base_pose, check_consistency, seed) -> dict(outcome, n_inliers, reproj, anchor_pose, lm_idx)
-       (HipShard below wraps an Engine; tests use an oracle-backed double)."""
+         scan(frame, base_pose, k, slot) -> (local ids (k,), counts (k,)) padded with -1 / 0
+         solve(local_ids, base_pose, check_consistency, seed, slot)
+             -> dict(outcome, n_inliers, reproj, anchor_pose, lm_idx)
+       `slot` names which of the batch's frames the call is about (solve works on the features the scan of the same
+       slot left behind); optional scan_batch(frames, base_poses, k) / solve_batch(jobs, base_poses, seeds) let a
+       backend overlap the frames of a batch (HipShard below does; tests use an oracle-backed double)."""
 
     def __init__(self, backend, shard_base: int, rank: int = 0, world: int = 1, group=None, device=None):
         self.backend, self.base, self.rank, self.world, self.group, self.device = backend, int(shard_base), rank, world, group, device
@@ -54,51 +57,101 @@ class ShardedRelocalizer:
         return np.stack([o.cpu().numpy() for o in out])
 
     def tick(self, frame, base_pose, seed: int = 0, k: int = K_GLOBAL):
-        lids, cnts = self.backend.scan(frame, base_pose, k)
-        gids = np.where(lids >= 0, lids + self.base, -1).astype(np.int64)
-        packed = np.stack([gids, cnts.astype(np.int64)])                      # (2, k) int64: 400 bytes
-        allp = self._all_gather(packed)                                       # (world, 2, k)
-        win_ids, win_cnt = merge_topk(allp[:, 0], allp[:, 1], k)
-        mine = [(pos, int(g - self.base)) for pos, g in enumerate(win_ids) if self._owns(int(g))]
-        res = np.zeros(12, np.float64)                                        # [pos, n_inl, reproj, outcome, gid, pose7]
-        res[0] = 1e9; res[3] = 3 if len(win_ids) else 2
-        if mine:
-            r = self.backend.solve([l for _, l in mine], base_pose, False, seed)
+        return self.tick_batch([frame], [base_pose], [seed], k)[0]
+
+    def tick_batch(self, frames, base_poses, seeds=None, k: int = K_GLOBAL):
+        """B frames, two collectives in total (BASELINE config 4: 8 frames per batch): one all-gather of the B local
+        top-k lists (B x 400 bytes per rank), one of the B result records (B x 96 bytes)."""
+        B = len(frames)
+        seeds = list(seeds) if seeds is not None else [0] * B
+        be = self.backend
+        if hasattr(be, "scan_batch"):
+            scans = be.scan_batch(frames, base_poses, k)
+        else:
+            scans = [be.scan(frames[i], base_poses[i], k, i) for i in range(B)]
+        packed = np.zeros((B, 2, k), np.int64)
+        for i, (lids, cnts) in enumerate(scans):
+            packed[i, 0] = np.where(lids >= 0, lids + self.base, -1)
+            packed[i, 1] = cnts
+        allp = self._all_gather(packed)                                       # (world, B, 2, k)
+        winners, jobs = [], []
+        for i in range(B):
+            win_ids, _ = merge_topk(allp[:, i, 0], allp[:, i, 1], k)
+            mine = [(pos, int(g - self.base)) for pos, g in enumerate(win_ids) if self._owns(int(g))]
+            winners.append((win_ids, mine))
+            if mine:
+                jobs.append((i, [l for _, l in mine]))
+        if hasattr(be, "solve_batch"):
+            solved = be.solve_batch(jobs, base_poses, seeds)
+        else:
+            solved = [be.solve(ids, base_poses[i], False, seeds[i], i) for i, ids in jobs]
+        res = np.zeros((B, 12), np.float64)                                   # [pos, n_inl, reproj, outcome, gid, pose7]
+        for i in range(B):
+            res[i, 0] = 1e9
+            res[i, 3] = 3 if len(winners[i][0]) else 2
+        for (i, _), r in zip(jobs, solved):
+            mine = winners[i][1]
             if r["outcome"] in (0, 4):
                 pos = next(p for p, l in mine if l == r["lm_idx"])
-                res[:5] = [pos, r["n_inliers"], r["reproj"], r["outcome"], r["lm_idx"] + self.base]
-                res[5:] = r["anchor_pose"]
+                res[i, :5] = [pos, r["n_inliers"], r["reproj"], r["outcome"], r["lm_idx"] + self.base]
+                res[i, 5:] = r["anchor_pose"]
             elif r["outcome"] == 1:
-                res[3] = 1
-        allr = self._all_gather(res)
-        if (allr[:, 3] == 1).any():
-            return dict(outcome=1, n_inliers=0, reproj=0.0, anchor_pose=np.zeros(7), lm_idx=-1, n_candidates=len(win_ids))
-        ok = allr[:, 1] > 0
-        if not ok.any():
-            return dict(outcome=int(res[3]), n_inliers=0, reproj=0.0, anchor_pose=np.zeros(7), lm_idx=-1,
-                        n_candidates=len(win_ids))
-        # most inliers, earliest in the global candidate order on ties (reference M:379)
-        best = min(np.nonzero(ok)[0], key=lambda i: (-allr[i, 1], allr[i, 0]))
-        b = allr[best]
-        return dict(outcome=int(b[3]), n_inliers=int(b[1]), reproj=float(b[2]), anchor_pose=b[5:].copy(), lm_idx=int(b[4]),
-                    n_candidates=len(win_ids))
+                res[i, 3] = 1
+        allr = self._all_gather(res)                                          # (world, B, 12)
+        out = []
+        for i in range(B):
+            ar, n_cand = allr[:, i], len(winners[i][0])
+            none = dict(n_inliers=0, reproj=0.0, anchor_pose=np.zeros(7), lm_idx=-1, n_candidates=n_cand)
+            if (ar[:, 3] == 1).any():
+                out.append(dict(outcome=1, **none))
+                continue
+            ok = ar[:, 1] > 0
+            if not ok.any():
+                out.append(dict(outcome=int(res[i, 3]), **none))
+                continue
+            # most inliers, earliest in the global candidate order on ties (reference M:379)
+            best = min(np.nonzero(ok)[0], key=lambda j: (-ar[j, 1], ar[j, 0]))
+            b = ar[best]
+            out.append(dict(outcome=int(b[3]), n_inliers=int(b[1]), reproj=float(b[2]), anchor_pose=b[5:].copy(),
+                            lm_idx=int(b[4]), n_candidates=n_cand))
+        return out
 
     def _owns(self, gid: int) -> bool:
         return self.base <= gid < self.base + self.backend.n_records
 
 
 class HipShard:
-    """One rank's shard on its GPU.  `frame` is a device pointer to a (H, W, 3) uint8 BGR image."""
+    """One rank's shard on its GPU.  `frame` is a device pointer to a (H, W, 3) uint8 BGR image.  n_slots > 1 keeps
+    that many contexts (each with the shard uploaded and its own stream) so the frames of a batch overlap."""
 
-    def __init__(self, engine, desc, pts3d, offsets, poses, rank: int, world: int, w=640, h=480):
+    def __init__(self, engine, desc, pts3d, offsets, poses, rank: int, world: int, w=640, h=480, n_slots: int = 1):
+        from .engine import Engine
         bounds = shard_by_rows(offsets, world)
         a, b = int(bounds[rank]), int(bounds[rank + 1])
         off = np.asarray(offsets[a:b + 1], np.int64) - int(offsets[a])
-        engine.db_upload(desc[offsets[a]:offsets[b]], pts3d[offsets[a]:offsets[b]], off, poses[a:b])
+        self.engines = [engine] + [Engine(engine.device, engine.max_w, engine.max_h, engine.max_feat) for _ in range(n_slots - 1)]
+        for e in self.engines:
+            e.db_upload(desc[offsets[a]:offsets[b]], pts3d[offsets[a]:offsets[b]], off, poses[a:b])
         self.engine, self.base, self.n_records, self.w, self.h = engine, a, b - a, w, h
 
-    def scan(self, frame_dev, base_pose, k):
-        return self.engine.tick_scan(frame_dev, self.w, self.h, base_pose, k)
+    def scan(self, frame_dev, base_pose, k, slot=0):
+        return self.engines[slot].tick_scan(frame_dev, self.w, self.h, base_pose, k)
 
-    def solve(self, local_ids, base_pose, check_consistency, seed):
-        return self.engine.tick_solve(local_ids, base_pose, check_consistency, seed)
+    def solve(self, local_ids, base_pose, check_consistency, seed, slot=0):
+        return self.engines[slot].tick_solve(local_ids, base_pose, check_consistency, seed)
+
+    def scan_batch(self, frames_dev, base_poses, k):
+        if len(frames_dev) > len(self.engines):
+            raise ValueError(f"batch of {len(frames_dev)} frames on a shard with {len(self.engines)} slots")
+        for i, f in enumerate(frames_dev):
+            self.engines[i].tick_scan_enqueue(f, self.w, self.h, base_poses[i], k)
+        return [self.engines[i].tick_scan_fetch(k) for i in range(len(frames_dev))]
+
+    def solve_batch(self, jobs, base_poses, seeds):
+        for i, ids in jobs:
+            self.engines[i].tick_solve_enqueue(ids, base_poses[i], False, seeds[i])
+        return [self.engines[i].tick_result() for i, _ in jobs]
+
+    def close(self):
+        for e in self.engines[1:]:
+            e.close()

@@ -28,6 +28,15 @@ def test_scan_solve_equals_fused_tick(engine, oracle):
     sr = ShardedRelocalizer(shard, shard.base, 0, 1)
     r = sr.tick(frame_dev, bp, seed=5)
     engine.dev_free(frame_dev)
+    # the same frame three times as one batch on a three-slot shard: identical to the single-frame exchange
+    shard3 = HipShard(engine, desc, pts, off, poses, rank=0, world=1, n_slots=3)
+    frame_dev = engine.to_device(img)
+    rb = ShardedRelocalizer(shard3, shard3.base, 0, 1).tick_batch([frame_dev] * 3, [bp] * 3, seeds=[5, 5, 5])
+    engine.dev_free(frame_dev)
+    shard3.close()
+    for x in rb:
+        assert x["outcome"] == r["outcome"] and x["n_inliers"] == r["n_inliers"] and x["lm_idx"] == r["lm_idx"]
+        np.testing.assert_array_equal(x["anchor_pose"], r["anchor_pose"])
     assert r["n_candidates"] == fused["n_candidates"] == len(exp_ids)
     assert (r["outcome"] in (0, 4)) == (fused["outcome"] in (0, 4))
     if fused["outcome"] in (0, 4):

@@ -29,11 +29,11 @@ class OracleShard:
         self.n_records = b - a
         self.math = math
 
-    def scan(self, frame, base_pose, k):
+    def scan(self, frame, base_pose, k, slot=0):
         gray = self.cv2.cvtColor(frame, self.cv2.COLOR_BGR2GRAY)
         kps, desc = self.core.orb.detectAndCompute(gray, None)
-        self.desc = desc
-        self.pts2d = np.array([kp.pt for kp in kps], dtype=np.float32)
+        self.feat = getattr(self, "feat", {})
+        self.feat[slot] = (desc, np.array([kp.pt for kp in kps], dtype=np.float32))
         herr = self.core.heading_errors(base_pose)
         scored = []
         for li in np.where(herr < self.math.radians(90.0))[0]:
@@ -49,10 +49,11 @@ class OracleShard:
             ids[i] = li; cnt[i] = n
         return ids, cnt
 
-    def solve(self, local_ids, base_pose, check_consistency, seed):
+    def solve(self, local_ids, base_pose, check_consistency, seed, slot=0):
         best = None
+        desc, pts2d = self.feat[slot]
         for li in local_ids:
-            r = self.core.solve_candidate(int(li), self.desc, self.pts2d, relocating=True)
+            r = self.core.solve_candidate(int(li), desc, pts2d, relocating=True)
             if r is not None and (best is None or r[0] > best[0]):
                 best = (*r, int(li))
         if best is None:
@@ -83,6 +84,9 @@ def _database():
     return data, scene
 
 
+POSES = [(5.0, 9.0, 2.0), (4.6, 0.25, 3.0), (6.0, -9.5, -3.0)]
+
+
 def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -94,14 +98,18 @@ def _worker(rank, world, port, out_path):
     bounds = LM.shard_by_rows(off, world)
     a, b = int(bounds[rank]), int(bounds[rank + 1])
     sr = ShardedRelocalizer(OracleShard(data, a, b), a, rank, world)
+    def plain(r):
+        return dict(outcome=r["outcome"], n_inliers=r["n_inliers"], lm_idx=r["lm_idx"],
+                    anchor=[float(v) for v in r["anchor_pose"]], n_candidates=r["n_candidates"])
     results = []
-    for pose in [(5.0, 9.0, 2.0), (4.6, 0.25, 3.0), (6.0, -9.5, -3.0)]:
+    for pose in POSES:
         bp = synth.base_pose(*pose)
-        r = sr.tick(scene.render(bp)[0], bp)
-        results.append(dict(outcome=r["outcome"], n_inliers=r["n_inliers"], lm_idx=r["lm_idx"],
-                            anchor=[float(v) for v in r["anchor_pose"]], n_candidates=r["n_candidates"]))
+        results.append(plain(sr.tick(scene.render(bp)[0], bp)))
+    # the same three frames as ONE batch: two collectives in total instead of six
+    bps = [synth.base_pose(*p) for p in POSES]
+    batch = [plain(r) for r in sr.tick_batch([scene.render(bp)[0] for bp in bps], bps)]
     if rank == 0:
-        json.dump(dict(bounds=[int(x) for x in bounds], results=results), open(out_path, "w"))
+        json.dump(dict(bounds=[int(x) for x in bounds], results=results, batch=batch), open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -119,7 +127,8 @@ def test_two_rank_gloo_equals_single_rank(oracle, tmp_path):
     assert 0 < got["bounds"][1] < 12
     data, scene = _database()
     single = ShardedRelocalizer(OracleShard(data, 0, len(data["landmarks"])), 0, 0, 1)
-    for pose, g in zip([(5.0, 9.0, 2.0), (4.6, 0.25, 3.0), (6.0, -9.5, -3.0)], got["results"]):
+    assert got["batch"] == got["results"]                       # batched exchange == per-frame exchange
+    for pose, g in zip(POSES, got["results"]):
         bp = synth.base_pose(*pose)
         e = single.tick(scene.render(bp)[0], bp)
         assert g["outcome"] == e["outcome"] and g["n_inliers"] == e["n_inliers"] and g["lm_idx"] == e["lm_idx"]
