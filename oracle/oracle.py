@@ -217,6 +217,11 @@ def match_knn2(q, t):
     return idx, dist
 
 
+def set_threads(n: int):
+    """threads of the whole-database scan (the only multi-threaded oracle routine); default 1"""
+    lib().orc_set_threads(int(n))
+
+
 def db_match_counts(db, offsets, cur):
     db = _u8(db); cur = _u8(cur)
     offsets = np.ascontiguousarray(offsets, np.int64)

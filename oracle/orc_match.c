@@ -19,6 +19,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/reloc_spec.h"
 
@@ -98,6 +101,11 @@ ORC_API int orc_match_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, i
  * :329-344): number of mutual matches of every record against the current frame's descriptors.
  * Record r owns teach descriptors [offsets[r], offsets[r+1]).  query = teach record rows,
  * train = current-frame rows, exactly as matcher.match(desc_t, desc_curr). */
+/* Records are independent, so the scan is also the one place the oracle uses more than one core
+ * (bench.py's cpu_baseline states the thread count; orc_set_threads(1) gives the scalar port). */
+static int g_threads = 1;
+ORC_API void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 ORC_API int orc_db_match_counts(const uint8_t *db, const int64_t *offsets, int64_t n_rec,
                                 const uint8_t *cur, int n_cur, int32_t *counts)
 {
@@ -106,14 +114,18 @@ ORC_API int orc_db_match_counts(const uint8_t *db, const int64_t *offsets, int64
         int64_t n = offsets[r + 1] - offsets[r];
         if (n > cap) cap = (int)n;
     }
-    int32_t *qi = malloc(sizeof(int32_t) * (size_t)cap), *ti = malloc(sizeof(int32_t) * (size_t)cap);
-    int32_t *dd = malloc(sizeof(int32_t) * (size_t)cap);
-    for (int64_t r = 0; r < n_rec; ++r) {
-        int32_t n = 0;
-        orc_match_mutual(db + 32 * offsets[r], (int)(offsets[r + 1] - offsets[r]), cur, n_cur, qi, ti, dd, &n);
-        counts[r] = n;
+#pragma omp parallel num_threads(g_threads)
+    {
+        int32_t *qi = malloc(sizeof(int32_t) * (size_t)cap), *ti = malloc(sizeof(int32_t) * (size_t)cap);
+        int32_t *dd = malloc(sizeof(int32_t) * (size_t)cap);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t r = 0; r < n_rec; ++r) {
+            int32_t n = 0;
+            orc_match_mutual(db + 32 * offsets[r], (int)(offsets[r + 1] - offsets[r]), cur, n_cur, qi, ti, dd, &n);
+            counts[r] = n;
+        }
+        free(qi); free(ti); free(dd);
     }
-    free(qi); free(ti); free(dd);
     return 0;
 }
 
