@@ -420,11 +420,12 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
     const size_t lds = (size_t)(ncb * CB + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
-    // 2.5 generations of resident workgroups (4 per CU are resident): measured best on MI355X for both the
-    // stand-alone scan (finer load balance than one resident generation, 192 -> 183 us) and for several
-    // contexts sharing the chip (slots turn over, other streams' kernels get in); beyond ~12 per CU the
-    // per-workgroup prologue (reload of the 500 current descriptors) costs more than the balance gains.
-    int grid = ctx->num_cu * 10;
+    // 4 generations of resident workgroups (4 per CU are resident): measured best on MI355X both for the
+    // stand-alone scan (finer load balance than one resident generation, 192 -> 175 us) and for several
+    // contexts sharing the chip (slots turn over, other streams' kernels get in: 1 / 2.5 / 4 / 6 generations
+    // give 4400 / 4750 / 4880 / 4825 frames/s in bench.py); beyond that the per-workgroup prologue (reload
+    // of the 500 current descriptors) costs more than the balance gains.
+    int grid = ctx->num_cu * 16;
     if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer switch
     if (grid > n_ids_max) grid = n_ids_max;
     if (m_qidx)
