@@ -11,13 +11,15 @@
 // three-operand VOP3 (v_lshl_or, v_min3, v_add3...) take ~4.2.  The kernels are built around that:
 //   - the accumulate form  v_bcnt_u32_b32 D, S0, S1 (D = popcount(S0) + S1)  keeps a 256-bit pair
 //     at 8 xor + 8 bcnt (about 54 cycles per 64 pairs per SIMD: the floor of this problem);
-//   - the argmin bookkeeping uses 16-bit keys (distance << 4 | index) with v_lshlrev_b16, v_or_b32
-//     and v_min_u16, all in the cheap class.
+//   - the argmin bookkeeping uses ONE 16-bit key per pair for both directions
+//     (distance << 7 | row-in-chunk << 3 | column slot) with v_lshlrev_b16, v_or_b32 and two
+//     v_min_u16, all in the cheap class.
 // Hot kernel (k_db_scan): a wave keeps all 512 current-frame descriptors (8 per lane, 64 VGPRs);
 // a database record's teach rows are wave-uniform, arrive through the scalar cache
-// (s_load_dwordx16) and feed the VALU as SGPR operands, so one 32-byte scalar fetch pays for 512
-// pairs and no LDS traffic is in the inner loop.  A record's rows are dealt in 16-row chunks to
-// the 4 waves of a workgroup.  Per chunk a wave produces (a) per lane and column the best row
+// (s_load_dwordx8, the fetch of row t+1 issued as soon as row t has landed) and feed the VALU as
+// SGPR operands, so one 32-byte scalar fetch pays for 512 pairs and no LDS traffic is in the
+// inner loop.  A record's rows are dealt to the 4 waves of a workgroup as balanced contiguous
+// ranges, walked in 16-row chunks (4-row chunks at the end).  Per chunk a wave produces (a) per lane and column the best row
 // (running 16-bit minimum), merged into LDS with ds_min_u32, and (b) per row the best column:
 // an in-lane 8-way 16-bit minimum, then a register-tile butterfly across lanes
 // (v_permlane16_swap / ds_bpermute).  Mutual nearest neighbours are resolved in LDS; the kernel
@@ -193,8 +195,9 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // grid: any; block: 256 (4 waves).  Dynamic LDS: (ncb*64*NJ + max_rows + 16) * 4 bytes.
 // NJ = columns per lane.  A wave covers a "column block" of 64*NJ current descriptors.  When the
 // number of column blocks ncb divides 4, wave w is bound to block w % ncb for the whole launch (its
-// descriptors stay in registers) and takes the 16-row chunks w / ncb, w / ncb + 4 / ncb, ...;
+// descriptors stay in registers) and shares a record's rows with the other waves bound to that block;
 // otherwise every wave walks all column blocks and reloads its registers per block.
+// mask.xyh != NULL: heading-incompatible records are not scored (count 0), see ScanMask.
 // NJ = 8 (the only instantiation): 500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per
 // SIMD.  NJ = 4 (two blocks, 8 waves per SIMD) was measured slower on MI355X (188 vs 176 us) and dropped.
 template <int NJ, bool EMIT>

@@ -211,16 +211,16 @@ __global__ __launch_bounds__(256) void k_blur7(const OrbTable *__restrict__ tab,
 }
 
 // ---- FAST + NMS ---------------------------------------------------------------------------------
-__device__ int fast_score(const uint8_t *p, int stride, int thr)
+// segment test: 0 = not a corner, +1 = 9 contiguous brighter, -1 = 9 contiguous darker ring pixels
+__device__ int fast_is_corner(const uint8_t *p, int stride, int thr)
 {
     const int c = p[0];
-    int v[16];
     u32 bright = 0, dark = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        v[k] = (int)p[c_ring_dy[k] * stride + c_ring_dx[k]] - c;
-        bright |= (u32)(v[k] > thr) << k;
-        dark |= (u32)(v[k] < -thr) << k;
+        const int v = (int)p[c_ring_dy[k] * stride + c_ring_dx[k]] - c;
+        bright |= (u32)(v > thr) << k;
+        dark |= (u32)(v < -thr) << k;
     }
     // 9 contiguous set bits on the 16-bit circle
     auto run9 = [](u32 m) {
@@ -231,12 +231,17 @@ __device__ int fast_score(const uint8_t *p, int stride, int thr)
         y &= x >> 8;          // runs of 9
         return (y & 0xFFFFu) != 0;
     };
-    const bool b = run9(bright), d = run9(dark);
-    if (!b && !d) return 0;
-    if (d) {
+    return run9(bright) ? 1 : (run9(dark) ? -1 : 0);
+}
+
+// corner score of a pixel that passed the segment test with polarity `sign`: the largest threshold it still
+// passes, i.e. max over the 16 arcs of 9 of the arc's minimum |difference|, minus 1
+__device__ int fast_corner_score(const uint8_t *p, int stride, int thr, int sign)
+{
+    const int c = p[0];
+    int v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = -v[k];
-    }
+    for (int k = 0; k < 16; ++k) v[k] = sign * ((int)p[c_ring_dy[k] * stride + c_ring_dx[k]] - c);
     int m2[16], m4[16], best = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) m2[k] = min(v[k], v[(k + 1) & 15]);
@@ -257,6 +262,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const OrbTable *__restrict__ t
 {
     __shared__ uint8_t s_img[(FT + 8) * (FT + 12)];
     __shared__ uint8_t s_sc[(FT + 2) * (FT + 4)];
+    __shared__ unsigned short s_corner[(FT + 2) * (FT + 2)];
+    __shared__ int s_nc;
     __shared__ int s_hist[256];
     const int l = find_level(tab->fast_tile_base, blockIdx.x);
     const OrbLevel L = tab->lev[l];
@@ -282,14 +289,25 @@ __global__ __launch_bounds__(256) void k_fast_nms(const OrbTable *__restrict__ t
         s_img[ry * IS + rx] = src[(size_t)gy * L.stride + gx];
     }
     __syncthreads();
+    // segment test for every pixel of the tile + 1-px ring; the few corners are compacted into a list so that
+    // the score (as long as the test itself) runs on full waves of corners instead of on every wave that
+    // happens to contain one
     const int SS = FT + 4;
+    if (tid == 0) s_nc = 0;
+    __syncthreads();
     for (int i = tid; i < (FT + 2) * (FT + 2); i += 256) {
         const int ry = i / (FT + 2), rx = i % (FT + 2);
         const int gy = y0 + ry - 1, gx = x0 + rx - 1;
-        int sc = 0;
+        int pol = 0;
         if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3)
-            sc = fast_score(s_img + (ry + 3) * IS + (rx + 3), IS, RELOC_FAST_THRESHOLD);
-        s_sc[ry * SS + rx] = (uint8_t)sc;
+            pol = fast_is_corner(s_img + (ry + 3) * IS + (rx + 3), IS, RELOC_FAST_THRESHOLD);
+        s_sc[ry * SS + rx] = 0;
+        if (pol) s_corner[atomicAdd(&s_nc, 1)] = (unsigned short)((ry << 6) | rx | (pol < 0 ? 0x8000 : 0));
+    }
+    __syncthreads();
+    for (int i = tid; i < s_nc; i += 256) {
+        const int e16 = s_corner[i], ry = (e16 >> 6) & 63, rx = e16 & 63;
+        s_sc[ry * SS + rx] = (uint8_t)fast_corner_score(s_img + (ry + 3) * IS + (rx + 3), IS, RELOC_FAST_THRESHOLD, (e16 & 0x8000) ? -1 : 1);
     }
     __syncthreads();
     {

@@ -33,7 +33,11 @@ def fail(kind, info):
     sys.exit(1)
 
 
+t_report = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_report:                    # a progress line per minute (a silent GPU job is taken to be hung)
+        print("progress", sum(n_case.values()), "cases", flush=True)
+        t_report = time.time() + 60
     kind = rng.choice(list(n_case))
     n_case[kind] += 1
     if kind == "match":
