@@ -174,16 +174,18 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
             cb16[j + 1] = min_u16(cb16[j + 1], k1);
             best = j == 0 ? min_u16(k0, k1) : min_u16(best, min_u16(k0, k1));   // best column of this row
         }
-        // 32-bit cross-lane key: distance << 16 | column
-        rk[t] = ((best >> 7) << 16) | (colbase + ((best & 7u) << 6) + (u32)lane);
+        // 32-bit cross-lane key: best << 9 | lane = distance << 16 | t << 12 | slot << 9 | lane.  The row bits
+        // are equal across the lanes of one row, and (slot, lane) orders like the column slot * 64 + lane
+        rk[t] = (best << 9) | (u32)lane;
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < R) { a = na; b = nb; }
     }
     const u32 m = rows_min<R>(rk, lane);
     const int row = tc + (lane & (R - 1));
     if (lane < R && row < n) {
-        if (single_cb) rowkey[row] = m;
-        else atomicMin(&rowkey[row], m);
+        const u32 key = (m & 0xFFFF0000u) | (colbase + ((m >> 9) & 7u) * 64u + (m & 63u));   // distance << 16 | column
+        if (single_cb) rowkey[row] = key;
+        else atomicMin(&rowkey[row], key);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
