@@ -354,7 +354,7 @@ def main():
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
                                   frac=pairs / scan_s / valu_peak_pairs,
                                   basis="measured chip ceiling of 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair "
-                                        "(tools/ubench_chain.hip); the kernel issues 21.1 VALU instructions per pair instead of 16 "
+                                        "(tools/ubench_chain.hip); the kernel issues 20.6 VALU instructions per pair instead of 16 "
                                         "(argmin bookkeeping) and runs 4 waves/SIMD, where the same ubench tops out at 2.3e12"))
         stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan=scan_s * 1e6, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
         roofline_matrix = None
