@@ -77,6 +77,42 @@ struct PnpOut {
     int32_t n_matches;
 };
 
+// ---- wave-wide reductions in the VALU's DPP network -------------------------------------------------
+// quad_perm / mirror steps leave a row's result in all of its 16 lanes, row_bcast15 / row_bcast31 carry it
+// across the four rows, lane 63 ends with the total.  A chain of such reductions costs a few VALU
+// instructions each instead of six dependent ds_bpermute round trips.  All 64 lanes must be active.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    int x = (int)v;
+#define RELOC_DPP_STEP(ctrl, rmask)                                                                     \
+    {                                                                                                   \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xF, false);         \
+        x = (int)((unsigned)x > o ? (unsigned)x : o);                                                    \
+    }
+    RELOC_DPP_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    RELOC_DPP_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    RELOC_DPP_STEP(0x141, 0xF)   // row_half_mirror
+    RELOC_DPP_STEP(0x140, 0xF)   // row_mirror
+    RELOC_DPP_STEP(0x142, 0xA)   // row_bcast15 -> rows 1, 3
+    RELOC_DPP_STEP(0x143, 0xC)   // row_bcast31 -> rows 2, 3
+#undef RELOC_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
+// integer sum (exact in any order); every lane gets the total
+__device__ __forceinline__ int wave_sum_i32(int x)
+{
+#define RELOC_DPP_STEP(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xF, false);
+    RELOC_DPP_STEP(0xB1, 0xF)
+    RELOC_DPP_STEP(0x4E, 0xF)
+    RELOC_DPP_STEP(0x141, 0xF)
+    RELOC_DPP_STEP(0x140, 0xF)
+    RELOC_DPP_STEP(0x142, 0xA)
+    RELOC_DPP_STEP(0x143, 0xC)
+#undef RELOC_DPP_STEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // ---- heading test shared by the scan and the candidate kernels (M:296-301, G:329-330) --------------
 __device__ __forceinline__ void quat_to_rot(double qx, double qy, double qz, double qw, double R[9])
 {

@@ -402,12 +402,9 @@ __device__ float harris_wave(const uint8_t *p, int step, int lane)
         const int iy = (q[step] - q[-step]) * 2 + (q[step - 1] - q[-step - 1]) + (q[step + 1] - q[-step + 1]);
         a = ix * ix; b = iy * iy; c = ix * iy;
     }
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) {
-        a += __shfl_xor(a, k);
-        b += __shfl_xor(b, k);
-        c += __shfl_xor(c, k);
-    }
+    a = wave_sum_i32(a);                  // integer sums: exact in any order
+    b = wave_sum_i32(b);
+    c = wave_sum_i32(c);
     const float scale = __fdiv_rn(1.f, (float)((1 << 2) * RELOC_HARRIS_BLOCK) * 255.f);
     const float s2 = __fmul_rn(scale, scale), s3 = __fmul_rn(s2, scale), s4 = __fmul_rn(s3, scale);
     const float fa = (float)a, fb = (float)b, fc = (float)c;
@@ -610,11 +607,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ t
                 m01 += v * I;
             }
         }
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) {
-            m10 += __shfl_xor(m10, k);
-            m01 += __shfl_xor(m01, k);
-        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     float sn, cs;

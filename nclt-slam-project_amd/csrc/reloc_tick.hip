@@ -57,28 +57,8 @@ constexpr int TOPK_MAX = 32;
 constexpr int TICK_BLOCK = 256, TICK_WAVES = TICK_BLOCK / 64;
 static_assert(MAX_CAND <= TOPK_MAX, "candidate slots");
 
-// Wave-wide maximum in the VALU's DPP network instead of six dependent ds_bpermute round trips: the
-// ranking loops below are chains of ~50 such reductions, so the latency of one reduction is the
-// kernel's run time (23 -> 6 us per ranking kernel).  quad_perm / mirror steps leave a row's maximum
-// in all of its 16 lanes, row_bcast15 / row_bcast31 carry it across the rows; lane 63 ends with the total.
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
-{
-    int x = (int)v;
-#define RELOC_DPP_MAX(ctrl, rmask)                                                                      \
-    {                                                                                                   \
-        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(x, x, ctrl, rmask, 0xF, false);         \
-        x = (int)((unsigned)x > o ? (unsigned)x : o);                                                    \
-    }
-    RELOC_DPP_MAX(0xB1, 0xF)    // quad_perm [1,0,3,2]
-    RELOC_DPP_MAX(0x4E, 0xF)    // quad_perm [2,3,0,1]
-    RELOC_DPP_MAX(0x141, 0xF)   // row_half_mirror
-    RELOC_DPP_MAX(0x140, 0xF)   // row_mirror
-    RELOC_DPP_MAX(0x142, 0xA)   // row_bcast15 -> rows 1, 3
-    RELOC_DPP_MAX(0x143, 0xC)   // row_bcast31 -> rows 2, 3
-#undef RELOC_DPP_MAX
-    return (unsigned)__builtin_amdgcn_readlane(x, 63);
-}
-
+// The ranking loops below are chains of ~50 wave reductions, so the latency of one reduction is the
+// kernel's run time: wave_max_u32 (DPP) instead of ds_bpermute butterflies took a ranking kernel from 23 to ~6 us.
 // keys are unique: the maximum is the largest low word among the lanes that hold the largest high word
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
