@@ -356,39 +356,39 @@ __device__ float harris_px(const uint8_t *p, int step)
 }
 
 // cut score from the level's histogram (KeyPointsFilter::retainBest(2*quota) with ties kept, raised
-// while the kept set exceeds RELOC_ORB_STAGE1_CAP).  All 256 threads participate.
-__device__ int stage1_cut(const int32_t *__restrict__ hist_l, int n_keep, int *s_suf, int *s_cut)
+// while the kept set exceeds RELOC_ORB_STAGE1_CAP), by ONE wave without block barriers: lane i owns the
+// bins 4i .. 4i+3.  c(s) = sum_{k >= s} hist[k] is non-increasing in s;
+//   cut0 = max{s : c(s) >= n_keep} if c(0) > n_keep, else the FAST threshold (everything is kept);
+//   cut  = min{s >= cut0 : c(s) <= CAP or s == 255}.
+// Every lane returns the cut.
+__device__ int stage1_cut_wave(const int32_t *__restrict__ hist_l, int n_keep, int lane)
 {
-    const int tid = threadIdx.x;
-    s_suf[tid] = hist_l[tid];
-    __syncthreads();
-    // inclusive suffix sum c(s) = sum_{k >= s} hist[k]
-    for (int d = 1; d < 256; d <<= 1) {
-        const int v = tid + d < 256 ? s_suf[tid + d] : 0;
-        __syncthreads();
-        s_suf[tid] += v;
-        __syncthreads();
+    const int4 h = *reinterpret_cast<const int4 *>(hist_l + 4 * lane);
+    // exclusive suffix sum of the lane totals
+    const int mine = h.x + h.y + h.z + h.w;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_down(incl, d);
+        if (lane + d < 64) incl += v;
     }
-    if (tid == 0) *s_cut = RELOC_FAST_THRESHOLD;
-    __syncthreads();
-    const int total = s_suf[0];
+    const int above = incl - mine;
+    const int c3 = h.w + above, c2 = h.z + c3, c1 = h.y + c2, c0 = h.x + c1;     // c(4i+3) .. c(4i)
+    const int total = __builtin_amdgcn_readlane(c0, 0);
+    int cut0 = RELOC_FAST_THRESHOLD;
     if (total > n_keep) {
-        // cut = max{s : c(s) >= n_keep}
-        const int cs = s_suf[tid], cn = tid + 1 < 256 ? s_suf[tid + 1] : 0;
-        if (cs >= n_keep && cn < n_keep) *s_cut = tid;
+        const int s = c3 >= n_keep ? 3 : (c2 >= n_keep ? 2 : (c1 >= n_keep ? 1 : (c0 >= n_keep ? 0 : -1)));
+        cut0 = (int)wave_max_u32(s < 0 ? 0u : (unsigned)(4 * lane + s + 1)) - 1;
     }
-    __syncthreads();
-    const int cut0 = *s_cut;
-    __syncthreads();
-    // smallest s >= cut0 with c(s) <= CAP (or 255)
-    {
-        const int cs = s_suf[tid];
-        const bool ok = tid >= cut0 && (cs <= RELOC_ORB_STAGE1_CAP || tid == 255);
-        const bool prev_ok = tid > cut0 && (s_suf[tid - 1] <= RELOC_ORB_STAGE1_CAP);
-        if (ok && !prev_ok) *s_cut = tid;
+    // smallest s >= cut0 with c(s) <= CAP (or 255): largest of 256 - s over the admissible bins
+    unsigned best = 0;
+    const int cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+        const int s = 4 * lane + k;
+        if (s >= cut0 && (cs[k] <= RELOC_ORB_STAGE1_CAP || s == 255)) best = (unsigned)(256 - s);
     }
-    __syncthreads();
-    return *s_cut;
+    return 256 - (int)wave_max_u32(best);
 }
 
 // Harris response of one pixel by a whole wave: lanes 0..48 own one pixel of the 7x7 block each.
@@ -421,7 +421,6 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
                                                 int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
                                                 float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
 {
-    __shared__ int s_suf[256];
     __shared__ int s_cut;
     __shared__ int s_n;
     __shared__ u32 s_list[4096];
@@ -435,8 +434,15 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
     const bool any = (v.x | v.y | v.z | v.w) != 0;
     if (threadIdx.x == 0) s_n = 0;
     if (!__syncthreads_or(any)) return;                      // nothing kept in this chunk: skip the cut computation
-    const int cut = stage1_cut(hist + l * 256, 2 * L.quota, s_suf, &s_cut);
-    if (dbg_cut && threadIdx.x == 0) dbg_cut[l] = cut;
+    if (threadIdx.x < 64) {
+        const int c = stage1_cut_wave(hist + l * 256, 2 * L.quota, threadIdx.x);
+        if (threadIdx.x == 0) {
+            s_cut = c;
+            if (dbg_cut) dbg_cut[l] = c;
+        }
+    }
+    __syncthreads();
+    const int cut = s_cut;
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
     if (any) {
 #pragma unroll
