@@ -47,7 +47,7 @@ __device__ __forceinline__ void cur_heading(const TickParams &prm, double &cc, d
 
 // Block-wide "k largest keys, descending" (keys unique, 0 = not eligible) without barriers in the
 // selection loops: every wave first extracts the k largest keys of ITS records (record i belongs to
-// thread (i - begin) mod TICK_BLOCK) with shuffles only -- per round one wave max-reduction, and only the lane that
+// thread (i - begin) mod TICK_BLOCK) -- per round one wave max-reduction (DPP), and only the lane that
 // owned the maximum moves on to its next key -- then wave 0 merges the per-wave winners the
 // same way.  One __syncthreads in total.  s_part: TICK_WAVES * TOPK_MAX entries.
 // The single-block tick kernels use 256 threads (one wave per SIMD): a block of that shape fits into the
@@ -125,8 +125,8 @@ __device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long 
 
 // ---- candidate selection ---------------------------------------------------------------------------
 // Two stages, so that a 10k-record database is not walked by one workgroup: k_topk_part gives every
-// TOPK_SLICE records to one block, which leaves its k best keys in topk_part; k_topk_final merges the
-// blocks' lists (or, for a database of one slice, ranks the records directly) and applies the mode's
+// TOPK_SLICE records to one block, which leaves its k best keys in topk_part; the mode's final kernel
+// (k_candidates_local / k_topk_counts) merges the blocks' lists (or, for a database of one slice, ranks the records directly) and applies the mode's
 // epilogue.  Keys are unique and 0 means "not eligible".
 //   local mode (M:293-302): nearest 15 by (distance, index), then the radius / heading filter in that
 //     order, first 5 kept.  Order key: the bit pattern of a non-negative double is monotone in its value;
