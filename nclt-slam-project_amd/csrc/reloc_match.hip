@@ -200,21 +200,18 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // descriptors stay in registers) and shares a record's rows with the other waves bound to that block;
 // otherwise every wave walks all column blocks and reloads its registers per block.
 // mask.xyh != NULL: heading-incompatible records are not scored (count 0), see ScanMask.
-// NJ = 8 (the only instantiation): 500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per
-// SIMD.  NJ = 4 (two blocks, 8 waves per SIMD) was measured slower on MI355X (188 vs 176 us) and dropped.
+// NJ = 8 is the working point (500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per SIMD);
+// NJ = 4 / 2 serve calls with at most 256 / 128 current descriptors, see k_db_scan.  (NJ = 4 with two blocks and 8 waves per SIMD for 500 descriptors was measured slower, 188 vs 176 us.)
 template <int NJ, bool EMIT>
-__global__ __launch_bounds__(256, 4) void k_db_scan(
-    const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
-    const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
-    const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
-    int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask)
+__device__ __forceinline__ void db_scan_body(
+    u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
+    const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
+    int32_t *__restrict__ counts, int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
+    int32_t *__restrict__ m_n, int emit_stride, const ScanMask &mask)
 {
-    extern __shared__ u32 lds[];
     constexpr int CB = 64 * NJ;           // columns per block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row fetches stay scalar
-    const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
     const int n_ids = n_ids_p ? min(*n_ids_p, n_ids_max) : n_ids_max;
     const int ncb = max((C + CB - 1) / CB, 1);
     u32 *colbest = lds;                   // ncb * CB : best (distance << 16 | row) per column
@@ -309,6 +306,25 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
             if (EMIT && m_n) m_n[it] = (int32_t)base;
         }
     }
+}
+
+// The kernel proper.  NJ is chosen by the host from the CAPACITY of the current-descriptor buffer: entry points
+// that know the query count (reloc_db_match_counts*, reloc_match_mutual) scan 128 or 256 columns per wave when
+// that is enough, so their cost follows the query count instead of being flat below 512; the fused tick passes
+// its feature capacity and always runs NJ = 8.  (One kernel branching on the device-side count was measured:
+// it costs the NJ = 8 path 3 %.)
+template <int NJ, bool EMIT>
+__global__ __launch_bounds__(256, 4) void k_db_scan(
+    const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
+    const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
+    const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
+    int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask)
+{
+    extern __shared__ u32 lds[];
+    const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
+    db_scan_body<NJ, EMIT>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
+                           emit_stride, mask);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,8 +424,6 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
     }
 }
 
-constexpr int SCAN_NJ = 8;
-
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
@@ -421,9 +435,10 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
     if (max_rows < 1) max_rows = 1;
-    constexpr int CB = 64 * SCAN_NJ;
-    const int ncb = (n_cur_max + CB - 1) / CB > 0 ? (n_cur_max + CB - 1) / CB : 1;
-    const size_t lds = (size_t)(ncb * CB + max_rows + 16) * 4;
+    const int nj = n_cur_max <= 128 ? 2 : (n_cur_max <= 256 ? 4 : 8);      // columns per lane, see k_db_scan
+    const int cb = 64 * nj;
+    const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;
+    const size_t lds = (size_t)(ncb * cb + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
     // 4 generations of resident workgroups (4 per CU are resident): measured best on MI355X both for the
     // stand-alone scan (finer load balance than one resident generation, 192 -> 175 us) and for several
@@ -433,14 +448,16 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     int grid = ctx->num_cu * 16;
     if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer switch
     if (grid > n_ids_max) grid = n_ids_max;
-    if (m_qidx)
-        hipLaunchKernelGGL((k_db_scan<SCAN_NJ, true>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
-    else
-        hipLaunchKernelGGL((k_db_scan<SCAN_NJ, false>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off,
-                           rec_ids, n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts,
-                           m_qidx, m_tidx, m_dist, m_n, emit_stride, mask);
+#define RELOC_LAUNCH_SCAN(NJ, EMIT)                                                                                          \
+    hipLaunchKernelGGL((k_db_scan<NJ, EMIT>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
+                       n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
+                       m_n, emit_stride, mask)
+    if (m_qidx) {
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, true); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true); else RELOC_LAUNCH_SCAN(8, true);
+    } else {
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, false); else if (nj == 4) RELOC_LAUNCH_SCAN(4, false); else RELOC_LAUNCH_SCAN(8, false);
+    }
+#undef RELOC_LAUNCH_SCAN
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
