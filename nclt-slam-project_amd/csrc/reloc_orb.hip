@@ -12,9 +12,10 @@
 // Launches per frame (all on the ctx stream):
 //   k_gray_l0 (or a 2-D copy)            3 B/px in, 1 B/px out, 4 px per lane (dword stores)
 //   k_resize  x7                         level l from level l-1, fixed-point INTER_LINEAR_EXACT
-//   k_blur7                              all levels, 64x16 tiles staged in LDS (8.8 / 16.16 passes)
-//   k_fast_nms                           all levels, 32x32 tiles + halo in LDS: score, 3x3 NMS,
-//                                        per-level score histogram (LDS atomics, then global)
+//   k_fast_blur                          one launch, two kinds of tiles over all levels:
+//                                        FAST 32x32 tiles + halo in LDS: segment test, scores of the compacted
+//                                        corners, 3x3 NMS, per-level score histogram (LDS atomics, then global);
+//                                        blur 64x16 tiles staged in LDS (8.8 / 16.16 passes)
 //   k_harris                             histogram -> cut score; survivors >= cut get a Harris
 //                                        response and enter the per-level candidate list
 //   k_select                             one workgroup per level: keep "fewer than quota strictly
@@ -169,14 +170,14 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src,
 
 // ---- blur ---------------------------------------------------------------------------------------
 constexpr int BT_W = 64, BT_H = 16;
-__global__ __launch_bounds__(256) void k_blur7(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
-                                               uint8_t *__restrict__ blur)
+__device__ __forceinline__ void blur7_tile(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                           uint8_t *__restrict__ blur, int bid)
 {
     __shared__ uint8_t s_in[(BT_H + 6) * (BT_W + 8)];
     __shared__ uint16_t s_h[(BT_H + 6) * BT_W];
-    const int l = find_level(tab->blur_tile_base, blockIdx.x);
+    const int l = find_level(tab->blur_tile_base, bid);
     const OrbLevel L = tab->lev[l];
-    const int tile = blockIdx.x - tab->blur_tile_base[l];
+    const int tile = bid - tab->blur_tile_base[l];
     const int tx = (L.w + BT_W - 1) / BT_W;
     const int x0 = (tile % tx) * BT_W, y0 = (tile / tx) * BT_H;
     const uint8_t *src = pyr + L.off;
@@ -257,17 +258,17 @@ __device__ int fast_corner_score(const uint8_t *p, int stride, int thr, int sign
 }
 
 constexpr int FT = 32;
-__global__ __launch_bounds__(256) void k_fast_nms(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
-                                                  uint8_t *__restrict__ nms, int32_t *__restrict__ hist)
+__device__ __forceinline__ void fast_nms_tile(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                              uint8_t *__restrict__ nms, int32_t *__restrict__ hist, int bid)
 {
     __shared__ uint8_t s_img[(FT + 8) * (FT + 12)];
     __shared__ uint8_t s_sc[(FT + 2) * (FT + 4)];
     __shared__ unsigned short s_corner[(FT + 2) * (FT + 2)];
     __shared__ int s_nc;
     __shared__ int s_hist[256];
-    const int l = find_level(tab->fast_tile_base, blockIdx.x);
+    const int l = find_level(tab->fast_tile_base, bid);
     const OrbLevel L = tab->lev[l];
-    const int tile = blockIdx.x - tab->fast_tile_base[l];
+    const int tile = bid - tab->fast_tile_base[l];
     const int tx = L.stride / FT;
     const int x0 = (tile % tx) * FT, y0 = (tile / tx) * FT;
     const int tid = threadIdx.x;
@@ -353,6 +354,16 @@ __device__ float harris_px(const uint8_t *p, int step)
     const float t4 = __fmul_rn(RELOC_HARRIS_K, t3), t5 = __fmul_rn(t4, t3);
     const float t6 = __fsub_rn(t1, t2), t7 = __fsub_rn(t6, t5);
     return __fmul_rn(t7, s4);
+}
+
+// FAST + NMS tiles and 7x7 blur tiles of all levels in ONE launch: both only read the pyramid, FAST feeds
+// Harris and the blur feeds the descriptors, so they need not run one after the other.
+__global__ __launch_bounds__(256) void k_fast_blur(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                   uint8_t *__restrict__ nms, int32_t *__restrict__ hist,
+                                                   uint8_t *__restrict__ blur, int n_fast)
+{
+    if ((int)blockIdx.x < n_fast) fast_nms_tile(tab, pyr, nms, hist, (int)blockIdx.x);
+    else blur7_tile(tab, pyr, blur, (int)blockIdx.x - n_fast);
 }
 
 // cut score from the level's histogram (KeyPointsFilter::retainBest(2*quota) with ties kept, raised
@@ -762,8 +773,8 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
                            ctx->rz_tab + tab_h->rz_off[l][1], ctx->rz_tab + tab_h->rz_off[l][2],
                            ctx->rz_tab + tab_h->rz_off[l][3]);
     }
-    hipLaunchKernelGGL(k_blur7, dim3(tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->blur);
-    hipLaunchKernelGGL(k_fast_nms, dim3(tab_h->fast_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->nms, ctx->hist);
+    hipLaunchKernelGGL(k_fast_blur, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr,
+                       ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV]);
     hipLaunchKernelGGL(k_harris, dim3(tab_h->flat_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->nms, ctx->hist,
                        ctx->cand_cnt, ctx->cand_key, ctx->cand_resp, ctx->dbg_cut);
     hipLaunchKernelGGL(k_select, dim3(NLEV), dim3(1024), 0, st, tab_d, ctx->cand_cnt,
