@@ -100,22 +100,21 @@ __device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long 
     __syncthreads();
     int n = 0;
     if (wave == 0) {
-        // lane l owns entries l, l + 64, ... of the TICK_WAVES * k per-wave winners
-        auto next_part = [&](unsigned long long bound) {
-            unsigned long long best = 0;
-            for (int e = lane; e < TICK_WAVES * k; e += 64) {
-                const unsigned long long key = s_part[(e / k) * TOPK_MAX + (e % k)];
-                if (key < bound && key > best) best = key;
-            }
-            return best;
-        };
-        unsigned long long mp = next_part(~0ull);
+        // lane l owns entries l and l + 64 of the TICK_WAVES * k <= 128 per-wave winners, sorted in two registers:
+        // taking a winner is a register move, nothing is rescanned
+        static_assert(TICK_WAVES * TOPK_MAX <= 128, "two entries per lane");
+        unsigned long long a0 = 0, a1 = 0;
+        for (int e = lane; e < TICK_WAVES * k; e += 64) {
+            const unsigned long long key = s_part[(e / k) * TOPK_MAX + (e % k)];
+            if (key > a0) { a1 = a0; a0 = key; }
+            else if (key > a1) a1 = key;
+        }
         for (int r = 0; r < k; ++r) {
-            const unsigned long long top = wave_max_u64(mp);
+            const unsigned long long top = wave_max_u64(a0);
             if (top == 0) break;
             if (lane == 0) out_keys[n] = top;
             ++n;
-            if (mp == top) mp = next_part(top);
+            if (a0 == top) { a0 = a1; a1 = 0; }
         }
         if (lane == 0) out_keys[TOPK_MAX] = (unsigned long long)n;
     }
