@@ -71,6 +71,35 @@ template <typename KeyFn>
 __device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long long *s_part, unsigned long long *out_keys)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // final pick, by wave 0: a lane holds up to four keys sorted in registers; taking a winner is a register move
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    auto hold = [&](unsigned long long key) {
+        unsigned long long t;
+        if (key > a0) { t = a0; a0 = key; key = t; }
+        if (key > a1) { t = a1; a1 = key; key = t; }
+        if (key > a2) { t = a2; a2 = key; key = t; }
+        if (key > a3) a3 = key;
+    };
+    auto pick = [&]() {
+        int n = 0;
+        for (int r = 0; r < k; ++r) {
+            const unsigned long long top = wave_max_u64(a0);
+            if (top == 0) break;
+            if (lane == 0) out_keys[n] = top;
+            ++n;
+            if (a0 == top) { a0 = a1; a1 = a2; a2 = a3; a3 = 0; }
+        }
+        if (lane == 0) out_keys[TOPK_MAX] = (unsigned long long)n;
+    };
+    if (end - begin <= 256) {
+        // few enough keys for one wave (the merge of the per-block lists of a 10k-record database is 250 keys)
+        if (wave == 0) {
+            for (int i = begin + lane; i < end; i += 64) hold(keyfn(i));
+            pick();
+        }
+        __syncthreads();
+        return (int)out_keys[TOPK_MAX];
+    }
     // every thread keeps the 4 largest of its own keys sorted in registers and rescans its records only
     // when all four have been taken (a thread rarely owns more than a few of the block's top k)
     unsigned long long m0, m1, m2, m3;
@@ -98,25 +127,11 @@ __device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long 
         }
     }
     __syncthreads();
-    int n = 0;
     if (wave == 0) {
-        // lane l owns entries l and l + 64 of the TICK_WAVES * k <= 128 per-wave winners, sorted in two registers:
-        // taking a winner is a register move, nothing is rescanned
-        static_assert(TICK_WAVES * TOPK_MAX <= 128, "two entries per lane");
-        unsigned long long a0 = 0, a1 = 0;
-        for (int e = lane; e < TICK_WAVES * k; e += 64) {
-            const unsigned long long key = s_part[(e / k) * TOPK_MAX + (e % k)];
-            if (key > a0) { a1 = a0; a0 = key; }
-            else if (key > a1) a1 = key;
-        }
-        for (int r = 0; r < k; ++r) {
-            const unsigned long long top = wave_max_u64(a0);
-            if (top == 0) break;
-            if (lane == 0) out_keys[n] = top;
-            ++n;
-            if (a0 == top) { a0 = a1; a1 = 0; }
-        }
-        if (lane == 0) out_keys[TOPK_MAX] = (unsigned long long)n;
+        // lane l owns entries l and l + 64 of the TICK_WAVES * k <= 128 per-wave winners
+        static_assert(TICK_WAVES * TOPK_MAX <= 256, "four entries per lane");
+        for (int e = lane; e < TICK_WAVES * k; e += 64) hold(s_part[(e / k) * TOPK_MAX + (e % k)]);
+        pick();
     }
     __syncthreads();
     return (int)out_keys[TOPK_MAX];
