@@ -99,6 +99,21 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
 
+// value of lane (l ^ K) for K = 1, 2, 4, 8 through DPP (quad permutes, row shifts with bank masks, row rotate)
+template <int K>
+__device__ __forceinline__ unsigned dpp_xor(unsigned v)
+{
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "in-row exchanges only");
+    const int x = (int)v;
+    if constexpr (K == 1) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);
+    else if constexpr (K == 2) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);
+    else if constexpr (K == 8) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);
+    else {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);      // banks 0, 2 <- lane + 4
+        return (unsigned)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);    // banks 1, 3 <- lane - 4
+    }
+}
+
 // integer sum (exact in any order); every lane gets the total
 __device__ __forceinline__ int wave_sum_i32(int x)
 {

@@ -111,7 +111,7 @@ __device__ __forceinline__ u32 bfly(u32 a, u32 b, int lane)
         const bool hi = lane & K;
         const u32 mine = hi ? b : a;
         const u32 theirs = hi ? a : b;
-        return umin(mine, (u32)__shfl_xor((int)theirs, K));
+        return umin(mine, dpp_xor<K>(theirs));
     }
 }
 
@@ -131,10 +131,14 @@ __device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
 #pragma unroll
     for (int i = 0; i < 2; ++i) d[i] = bfly<2>(d[i], d[i + 2], lane);
     u32 x = bfly<1>(d[0], d[1], lane);
-    if constexpr (R <= 4) x = umin(x, (u32)__shfl_xor((int)x, 4));
-    if constexpr (R <= 8) x = umin(x, (u32)__shfl_xor((int)x, 8));
-    x = umin(x, (u32)__shfl_xor((int)x, 16));
-    x = umin(x, (u32)__shfl_xor((int)x, 32));
+    if constexpr (R <= 4) x = umin(x, dpp_xor<4>(x));
+    if constexpr (R <= 8) x = umin(x, dpp_xor<8>(x));
+    {   // ^16, ^32: after a swap with itself the two results are the lane's value and its partner's
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        x = umin(r[0], r[1]);
+        const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        x = umin(q[0], q[1]);
+    }
     return x;
 }
 
