@@ -480,10 +480,14 @@ __global__ __launch_bounds__(64) void k_pnp_finish(const float *__restrict__ obj
                 if (found < 0 && bal) found = j * 64 + __ffsll((long long)bal) - 1;
             }
             if (found < 0) break;
-            const int ch = __shfl(cl[0], found & 63) * (found < 64) +
-                           (MAX_HYP > 64 ? __shfl(cl[1 % (MAX_HYP / 64)], found & 63) * (found >= 64 && found < 128) : 0) +
-                           (MAX_HYP > 128 ? __shfl(cl[2 % (MAX_HYP / 64)], found & 63) * (found >= 128 && found < 192) : 0) +
-                           (MAX_HYP > 192 ? __shfl(cl[3 % (MAX_HYP / 64)], found & 63) * (found >= 192) : 0);
+            // `found` is wave-uniform: read the winner's count with v_readlane instead of four ds_bpermute
+            const int fl = __builtin_amdgcn_readfirstlane(found) & 63, fj = __builtin_amdgcn_readfirstlane(found) >> 6;
+            int ch = 0;
+#pragma unroll
+            for (int j = 0; j < MAX_HYP / 64; ++j) {
+                const int cj = __builtin_amdgcn_readlane(cl[j], fl);
+                if (j == fj) ch = cj;
+            }
             s_best_v = found;
             best_count = ch;
             niters = ransac_update_iters(prm.conf, (double)(m - ch) / (double)m, niters);
