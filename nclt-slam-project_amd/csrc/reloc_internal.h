@@ -159,6 +159,10 @@ __device__ __forceinline__ void cur_heading_q(const double q[4], double &cc, dou
 struct ScanMask {
     const double *xyh;
     double q[4];
+    // emit mode only (M:333-336): when g_obj is set, every mutual match also leaves its 3-D / 2-D pair
+    // (keypoints_3d_cam[queryIdx], pts_curr_2d[trainIdx]) next to its index triplet, so no gather launch follows
+    const float *g_pts3d = nullptr, *g_xy = nullptr;
+    float *g_obj = nullptr, *g_img = nullptr;
 };
 
 struct reloc_ctx {

@@ -301,6 +301,12 @@ __device__ __forceinline__ void db_scan_body(
                 m_qidx[o] = row;
                 m_tidx[o] = (int32_t)(key & 0xFFFFu);
                 m_dist[o] = (int32_t)(key >> 16);
+                if (mask.g_obj) {
+                    const float *p3 = mask.g_pts3d + 3 * (row0 + row), *p2 = mask.g_xy + 2 * (size_t)(key & 0xFFFFu);
+                    float *po = mask.g_obj + 3 * o, *pi = mask.g_img + 2 * o;
+                    po[0] = p3[0]; po[1] = p3[1]; po[2] = p3[2];
+                    pi[0] = p2[0]; pi[1] = p2[1];
+                }
             }
             base += total;
             __syncthreads();
@@ -434,7 +440,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
                    int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask_p)
 {
     if (n_ids_max <= 0) return RELOC_OK;
-    ScanMask mask = {nullptr, {0, 0, 0, 1}};
+    ScanMask mask;
+    mask.xyh = nullptr;
+    mask.q[0] = mask.q[1] = mask.q[2] = 0; mask.q[3] = 1;
     if (mask_p) mask = *mask_p;
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }

@@ -266,29 +266,6 @@ static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t 
                        out_ids, out_counts, ctx->cand_n);
 }
 
-// ---- gather (M:333-336) ---------------------------------------------------------------------------
-// grid MAX_CAND, block 256: obj = keypoints_3d_cam[queryIdx], img = pts_curr_2d[trainIdx]
-__global__ __launch_bounds__(256) void k_gather(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
-                                                const int64_t *__restrict__ off, const float *__restrict__ pts3d,
-                                                const float *__restrict__ f_xy, const int32_t *__restrict__ m_qidx,
-                                                const int32_t *__restrict__ m_tidx, const int32_t *__restrict__ m_n,
-                                                float *__restrict__ p_obj, float *__restrict__ p_img)
-{
-    const int s = blockIdx.x;
-    if (s >= *cand_n) return;
-    const int r = cand_ids[s];
-    const int64_t row0 = off[r];
-    const int m = m_n[s];
-    for (int k = threadIdx.x; k < m; k += 256) {
-        const int64_t q = row0 + m_qidx[(size_t)s * MAX_REC_ROWS + k];
-        const int t = m_tidx[(size_t)s * MAX_REC_ROWS + k];
-        float *o = p_obj + ((size_t)s * MAX_REC_ROWS + k) * 3;
-        o[0] = pts3d[3 * q]; o[1] = pts3d[3 * q + 1]; o[2] = pts3d[3 * q + 2];
-        float *im = p_img + ((size_t)s * MAX_REC_ROWS + k) * 2;
-        im[0] = f_xy[2 * t]; im[1] = f_xy[2 * t + 1];
-    }
-}
-
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
 // one lane per candidate composes its pose; the best (most inliers, first on ties) is picked by a wave
 // reduction.
@@ -380,13 +357,15 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
 {
     int rc;
     hipStream_t st = ctx->stream;
-    // mutual matches of every candidate, in queryIdx order
+    // mutual matches of every candidate, in queryIdx order, with their 3-D / 2-D pairs (M:333-336)
+    ScanMask emit;
+    emit.xyh = nullptr;
+    emit.q[0] = emit.q[1] = emit.q[2] = 0; emit.q[3] = 1;
+    emit.g_pts3d = ctx->db_pts3d; emit.g_xy = ctx->f_xy; emit.g_obj = ctx->p_obj; emit.g_img = ctx->p_img;
     if ((rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
                              ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
-                             ctx->m_dist, ctx->m_n, MAX_REC_ROWS)))
+                             ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit)))
         return rc;
-    hipLaunchKernelGGL(k_gather, dim3(MAX_CAND), dim3(256), 0, st, ctx->cand_ids, ctx->cand_n, ctx->db_off, ctx->db_pts3d,
-                       ctx->f_xy, ctx->m_qidx, ctx->m_tidx, ctx->m_n, ctx->p_obj, ctx->p_img);
     if ((rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, RELOC_RANSAC_ITERATIONS, (float)RELOC_RANSAC_REPROJ_PX,
                                  RELOC_RANSAC_CONFIDENCE, seed, RELOC_MIN_MATCHES)))
         return rc;
@@ -416,7 +395,9 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
     const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, !global_reloc);
     if (global_reloc) {
         // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others)
-        ScanMask mask = {ctx->db_xy_heading, {base_pose[3], base_pose[4], base_pose[5], base_pose[6]}};
+        ScanMask mask;
+        mask.xyh = ctx->db_xy_heading;
+        for (int k = 0; k < 4; ++k) mask.q[k] = base_pose[3 + k];
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                             ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
@@ -467,8 +448,9 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
     if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
-    ScanMask mask = {nullptr, {0, 0, 0, 1}};
-    if (base_pose) mask = ScanMask{ctx->db_xy_heading, {base_pose[3], base_pose[4], base_pose[5], base_pose[6]}};
+    ScanMask mask;
+    mask.xyh = base_pose ? ctx->db_xy_heading : nullptr;
+    for (int k = 0; k < 4; ++k) mask.q[k] = base_pose ? base_pose[3 + k] : (k == 3 ? 1.0 : 0.0);
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                         ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0, &mask);
