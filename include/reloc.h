@@ -51,6 +51,31 @@ extern "C" {
 
 typedef struct reloc_ctx reloc_ctx;
 
+/* Matcher parameters of the fused tick: the module-level constants of the reference matcher (M:56-75, accumulation
+ * M:85-89, global relocalisation G:80-86).  reloc_create() installs the reference's values; a host that runs with
+ * other values (MatcherConfig in the Python layer) sets them here, so the fused device tick and the cv2-shaped path
+ * gate identically. */
+typedef struct reloc_params {
+    int32_t nfeatures;               /* ORB_create(nfeatures)                 M:207   500   */
+    int32_t max_candidates;          /* MAX_CANDIDATES (<= 10)                M:57    5     */
+    int32_t min_matches;             /* MIN_MATCHES                           M:65    10    */
+    int32_t min_inliers;             /* MIN_INLIERS                           M:70    10    */
+    int32_t ransac_iterations;       /* RANSAC_ITERATIONS (<= 1024)           M:69    200   */
+    int32_t global_max_candidates;   /* RELOC_MAX_CANDIDATES (<= 32)          G:84    25    */
+    int32_t global_min_inliers;      /* RELOC_MIN_INLIERS                     G:85    18    */
+    int32_t accum_min_kpts;          /* ACCUM_MIN_KPTS                        M:88    30    */
+    double candidate_radius_m;       /* CANDIDATE_RADIUS_M                    M:56    8.0   */
+    double heading_tol_deg;          /* HEADING_TOL_DEG                       M:58    90.0  */
+    double reproj_max_px;            /* REPROJ_ERR_MAX_PX                     M:67    2.0   */
+    double ransac_reproj_px;         /* RANSAC_REPROJ_PX                      M:68    3.0   */
+    double ransac_confidence;        /* cv2.solvePnPRansac default                    0.99  */
+    double consistency_m;            /* CONSISTENCY_M                         M:75    5.0   */
+    double global_reproj_max_px;     /* RELOC_REPROJ_MAX_PX                   G:86    1.5   */
+    double accum_min_dist_m;         /* ACCUM_MIN_DIST_M                      M:87    5.0   */
+    double accum_depth_min_m;        /* d_c > 0.5                             M:461   0.5   */
+    double accum_depth_max_m;        /* d_c < 15.0                            M:461   15.0  */
+} reloc_params;
+
 /* ---- lifetime, errors, plumbing ----------------------------------------------------------- */
 const char *reloc_last_error(void);
 int  reloc_device_count(void);
@@ -77,6 +102,9 @@ int  reloc_timer_end(reloc_ctx *ctx, float *ms);
 #define RELOC_PROF_N        4
 int  reloc_profile_enable(reloc_ctx *ctx, int on);
 int  reloc_profile_get(reloc_ctx *ctx, int which, float *total_ms, int32_t *launches);
+
+int  reloc_get_params(reloc_ctx *ctx, reloc_params *out);
+int  reloc_set_params(reloc_ctx *ctx, const reloc_params *p);
 
 /* ---- ORB front end ------------------------------------------------------------------------ */
 /* cv2.cvtColor(img, COLOR_BGR2GRAY)                                         M:305  R:240  S:44 */
@@ -131,6 +159,24 @@ int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, con
                     const double *poses, int64_t n_records);
 int64_t reloc_db_records(reloc_ctx *ctx);
 int64_t reloc_db_rows(reloc_ctx *ctx);
+/* The database lives in a capacity-reserved arena: appending a record (accumulation, M:435-500) copies its rows behind
+ * the last one and never re-allocates while the reserve lasts; reserve() grows the arena (device-to-device copy of
+ * the contents) and is also what upload/append call when the reserve is exhausted (geometric growth). */
+int reloc_db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows);
+/* self.landmarks.append(new_lm); self.xy = vstack(...); self.heading = append(...)        M:489-493
+ * desc n x 32, pts3d n x 3 (keypoints_3d_cam), kp2d n x 2 or NULL (keypoints_2d, kept for reloc_db_fetch), pose =
+ * camera pose x y z qx qy qz qw, index_xy = the (x, y) the candidate search files the record under (the reference
+ * files an accumulated record under the VIO position, M:491; NULL = pose x, y as for taught records M:213). */
+int reloc_db_append(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const float *kp2d, int n,
+                    const double pose[7], const double index_xy[2]);
+/* Two resident databases (slot 0 / 1): the split-landmark variant keeps the outbound set in one and the return-leg
+ * set in the other and flips at the turnaround (X:274-294).  upload / append / reserve / tick act on the selected
+ * slot; selecting costs nothing on the device. */
+int reloc_db_select(reloc_ctx *ctx, int slot);
+/* Read one record back (save of the augmented database M:502-514, parity taps).  Any output may be NULL; desc / pts3d /
+ * kp2d must hold the record's rows (query *n first with all arrays NULL). */
+int reloc_db_fetch(reloc_ctx *ctx, int64_t record, uint8_t *desc, float *pts3d, float *kp2d, double pose[7],
+                   double index_xyh[4], int32_t *n);
 /* Whole-database scan of G:329-344: per record, the number of mutual matches between the
  * record's descriptors (query) and the current frame's descriptors (train).  cur: n_cur x 32. */
 int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts);
@@ -166,8 +212,12 @@ int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double base_to_ca
                      const double base_to_cam_R[9]);
 
 /* ---- fused tick ----------------------------------------------------------------------------- */
-/* One repeat tick against the uploaded database (M:281-433 with G:315-344's whole-database
- * candidate search when global_reloc != 0): gray -> ORB -> candidates -> mutual match ->
+#define RELOC_TICK_LOCAL   0   /* candidates by VIO distance / heading only                          M:293-302 */
+#define RELOC_TICK_GLOBAL  1   /* whole-database search unconditionally (the benchmarked shape)       G:329-344 */
+#define RELOC_TICK_AUTO    2   /* local first; whole-database search only if it finds no candidate -- the host passes
+                                  this mode when G's silence and drift conditions hold                G:324-326 */
+/* One repeat tick against the selected database (M:281-433 with G:315-344's whole-database
+ * candidate search according to global_reloc = RELOC_TICK_*): gray -> ORB -> candidates -> mutual match ->
  * PnP-RANSAC -> reprojection gate -> pose compose -> best by inliers -> consistency gate.
  * base_pose: x y z qx qy qz qw of base_link (the /tmp/isaac_pose.txt line).
  * Outputs: anchor_pose[7] (base_link in the teach map), n_inl, reproj (px), lm_idx, outcome,
@@ -181,6 +231,18 @@ int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int ord
                    const double base_pose[7], int global_reloc, uint64_t seed);
 int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
                       int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
+/* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344). */
+int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
+                         int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating);
+/* Accumulation (M:435-500), enqueued behind a tick on the same ctx: when the tick's outcome is no_candidates /
+ * no_pnp_accept / consistency_fail (M:314,384,396), silence_ok is set (the host's `ts - last_anchor_ts >=
+ * ACCUM_SILENCE_S`, M:441) and no record is filed within accum_min_dist_m of the robot, the current frame's keypoints
+ * with valid depth become a new record at the tail of the arena (>= accum_min_kpts of them).  depth_mm_dev: (h, w)
+ * uint16 millimetres in device memory.  The arena must have room for one record of max_feat rows (reloc_db_reserve);
+ * reloc_accumulate_result() synchronises, reports what happened and makes the new record visible to later ticks. */
+int reloc_tick_accumulate_dev(reloc_ctx *ctx, const uint16_t *depth_mm_dev, int w, int h, const double base_pose[7],
+                              int silence_ok);
+int reloc_accumulate_result(reloc_ctx *ctx, int32_t *appended, int32_t *n_kpts, double *nearest_m);
 /* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12). */
 int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches,
                      int32_t *n_inl, int32_t *ok, double *reproj, double *Rt);

@@ -64,6 +64,13 @@
 #define RELOC_CONSISTENCY_M      5.0
 /* Global-relocalisation variant (experiments/63_global_reloc/scripts/visual_landmark_matcher.py) */
 #define RELOC_GLOBAL_MAX_CANDIDATES 25
+#define RELOC_GLOBAL_MIN_INLIERS    18        /* :85 */
+#define RELOC_GLOBAL_REPROJ_MAX_PX  1.5       /* :86 */
+/* Accumulation (visual_landmark_matcher.py:85-89, :461). */
+#define RELOC_ACCUM_MIN_DIST_M   5.0
+#define RELOC_ACCUM_MIN_KPTS     30
+#define RELOC_ACCUM_DEPTH_MIN_M  0.5
+#define RELOC_ACCUM_DEPTH_MAX_M  15.0
 
 /* Pinhole intrinsics (visual_landmark_matcher.py:49-52, visual_landmark_recorder.py:55-57). */
 #define RELOC_FX 320.0

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libreloc_hip.so")
+# RELOC_LIB: developer switch used by tools/exp_scan_variants.py to time experimental builds of the same library
+LIB_PATH = os.environ.get("RELOC_LIB") or os.path.join(_HERE, "csrc", "libreloc_hip.so")
 
 c_ctx = C.c_void_p
 P = C.c_void_p
@@ -57,11 +58,32 @@ SIGNATURES = {
     "reloc_set_camera": (C.c_int, [c_ctx, P, P, P]),
     "reloc_tick_debug": (C.c_int, [c_ctx, P, P, P, P, P, P, P]),
     "reloc_tick": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64, P, P, P, P, P, P]),
+    "reloc_get_params": (C.c_int, [c_ctx, P]),
+    "reloc_set_params": (C.c_int, [c_ctx, P]),
+    "reloc_db_reserve": (C.c_int, [c_ctx, i64, i64]),
+    "reloc_db_append": (C.c_int, [c_ctx, P, P, P, C.c_int, P, P]),
+    "reloc_db_select": (C.c_int, [c_ctx, C.c_int]),
+    "reloc_db_fetch": (C.c_int, [c_ctx, i64, P, P, P, P, P, P]),
+    "reloc_tick_result_ex": (C.c_int, [c_ctx, P, P, P, P, P, P, P, P]),
+    "reloc_tick_accumulate_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, P, C.c_int]),
+    "reloc_accumulate_result": (C.c_int, [c_ctx, P, P, P]),
     "reloc_tick_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64]),
     "reloc_tick_result": (C.c_int, [c_ctx, P, P, P, P, P, P]),
     "reloc_tick_scan_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, P, P, C.c_int]),
     "reloc_tick_solve_dev": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, u64]),
 }
+
+
+
+class RelocParams(C.Structure):
+    """mirror of `reloc_params` (include/reloc.h)"""
+    _fields_ = [("nfeatures", i32), ("max_candidates", i32), ("min_matches", i32), ("min_inliers", i32),
+                ("ransac_iterations", i32), ("global_max_candidates", i32), ("global_min_inliers", i32),
+                ("accum_min_kpts", i32), ("candidate_radius_m", f64), ("heading_tol_deg", f64), ("reproj_max_px", f64),
+                ("ransac_reproj_px", f64), ("ransac_confidence", f64), ("consistency_m", f64),
+                ("global_reproj_max_px", f64), ("accum_min_dist_m", f64), ("accum_depth_min_m", f64),
+                ("accum_depth_max_m", f64)]
+
 
 _lib = None
 

@@ -54,5 +54,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines: list[str], verbose: bool = False) -> str:
+    """Developer builds for kernel experiments: the whole library compiled with extra -D flags into
+    build_variants/libreloc_hip_<name>.so (git-ignored, travels to the GPU box).  Never loaded by the product path;
+    tools/exp_scan_variants.py selects one through RELOC_LIB."""
+    vdir = os.path.join(HERE, "..", "build_variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    objs, jobs = [], []
+    for s in sources():
+        obj = os.path.join(vdir, s[:-4] + ".o")
+        objs.append(obj)
+        jobs.append([HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    lib = os.path.join(vdir, "..", f"libreloc_hip_{name}.so")
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return os.path.abspath(lib)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -76,6 +76,10 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->p_inl, (int64_t)MAX_CAND * MAX_REC_ROWS);
     rc |= dalloc(&c->p_out, MAX_CAND);
     rc |= dalloc(&c->tick_res, 1);
+    rc |= dalloc(&c->accum_res, 1);
+    rc |= dalloc(&c->tick_flags, 4);
+    rc |= dalloc(&c->scan_ticket, 2);
+    if (rc == 0 && hipMemset(c->scan_ticket, 0, 8) != hipSuccess) rc = RELOC_E_HIP;
     return rc;
 }
 
@@ -109,6 +113,26 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
         return nullptr;
     }
     c->stream = c->own_stream;
+    // reference constants (include/reloc_spec.h); reloc_set_params overrides them
+    c->prm.nfeatures = 500;
+    c->prm.max_candidates = RELOC_MAX_CANDIDATES;
+    c->prm.min_matches = RELOC_MIN_MATCHES;
+    c->prm.min_inliers = RELOC_MIN_INLIERS;
+    c->prm.ransac_iterations = RELOC_RANSAC_ITERATIONS;
+    c->prm.global_max_candidates = RELOC_GLOBAL_MAX_CANDIDATES;
+    c->prm.global_min_inliers = RELOC_GLOBAL_MIN_INLIERS;
+    c->prm.accum_min_kpts = RELOC_ACCUM_MIN_KPTS;
+    c->prm.candidate_radius_m = RELOC_CANDIDATE_RADIUS_M;
+    c->prm.heading_tol_deg = RELOC_HEADING_TOL_DEG;
+    c->prm.reproj_max_px = RELOC_REPROJ_MAX_PX;
+    c->prm.ransac_reproj_px = RELOC_RANSAC_REPROJ_PX;
+    c->prm.ransac_confidence = RELOC_RANSAC_CONFIDENCE;
+    c->prm.consistency_m = RELOC_CONSISTENCY_M;
+    c->prm.global_reproj_max_px = RELOC_GLOBAL_REPROJ_MAX_PX;
+    c->prm.accum_min_dist_m = RELOC_ACCUM_MIN_DIST_M;
+    c->prm.accum_depth_min_m = RELOC_ACCUM_DEPTH_MIN_M;
+    c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
+    if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switch
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
         return nullptr;
@@ -123,12 +147,18 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
                     c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
-                    c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_off,
+                    c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off,
                     c->db_pose, c->db_xy_heading, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,
                     c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
-                    c->p_out, c->tick_res};
+                    c->p_out, c->tick_res, c->accum_res, c->tick_flags, c->scan_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    {   // the database that is not selected
+        const DbArena &a = c->db_slot[1 - c->db_sel];
+        void *q[] = {a.desc, a.pts3d, a.kp2d, a.off, a.pose, a.xy_heading, a.counts, a.topk_part};
+        for (void *p : q)
+            if (p) (void)hipFree(p);
+    }
     for (int i = 0; i < 8; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < RELOC_PROF_N; ++k)
@@ -141,6 +171,29 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+RELOC_API int reloc_get_params(reloc_ctx *c, reloc_params *out)
+{
+    ARG_CHECK_CTX(c, out, "reloc_get_params");
+    *out = c->prm;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_set_params(reloc_ctx *c, const reloc_params *p)
+{
+    ARG_CHECK_CTX(c, p, "reloc_set_params");
+    ARG_CHECK(p->nfeatures >= 1 && p->nfeatures <= c->max_feat, "nfeatures must be in [1, max_feat]");
+    ARG_CHECK(p->max_candidates >= 1 && p->max_candidates * 3 <= 32, "max_candidates must be in [1, 10]");
+    ARG_CHECK(p->global_max_candidates >= 1 && p->global_max_candidates <= MAX_CAND, "global_max_candidates must be in [1, 32]");
+    ARG_CHECK(p->ransac_iterations >= 1 && p->ransac_iterations <= MAX_HYP, "ransac_iterations must be in [1, 1024]");
+    ARG_CHECK(p->min_matches >= RELOC_PNP_SAMPLE && p->min_inliers >= 0 && p->global_min_inliers >= 0 && p->accum_min_kpts >= 1,
+              "min_matches must be >= 4, inlier / keypoint gates non-negative");
+    ARG_CHECK(p->candidate_radius_m >= 0 && p->heading_tol_deg >= 0 && p->heading_tol_deg <= 180 && p->ransac_reproj_px > 0 &&
+                  p->ransac_confidence > 0 && p->ransac_confidence < 1 && p->consistency_m >= 0 && p->accum_min_dist_m >= 0,
+              "a gate is out of range");
+    c->prm = *p;
+    return RELOC_OK;
 }
 
 RELOC_API int reloc_set_stream(reloc_ctx *c, void *hip_stream)

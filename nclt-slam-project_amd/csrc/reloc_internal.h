@@ -44,7 +44,8 @@ void reloc_set_error(const char *fmt, ...);
 constexpr int NLEV = RELOC_ORB_NLEVELS;
 constexpr int MAX_REC_ROWS = 4096;   // largest record (teach rows) the fused scan accepts
 constexpr int MAX_CAND = 32;         // PnP candidates per tick (5 local / 25 global)
-constexpr int MAX_HYP = 256;         // RANSAC hypotheses per candidate
+constexpr int MAX_HYP = 1024;        // RANSAC hypotheses per candidate (iterationsCount)
+constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps the record index in 20 bits
 
 struct OrbLevel {
     int w, h;          // level size
@@ -63,7 +64,30 @@ struct TickResult {
     int32_t outcome;
     int32_t n_candidates;
     int32_t n_features;
-    int32_t pad;
+    int32_t relocating;   // candidates came from the whole-database search (G:344)
+};
+
+// what reloc_tick_accumulate_dev left behind (device resident)
+struct AccumResult {
+    double nearest_m;     // distance to the nearest filed record (-1: not evaluated)
+    int32_t appended;     // 1: a record was written behind the arena's last one
+    int32_t n_kpts;       // keypoints with valid depth
+};
+
+// One resident landmark database: structure of arrays with reserved capacity (rows: cap_rows, records: cap_records).
+struct DbArena {
+    int64_t cap_records = 0, cap_rows = 0;
+    int64_t records = 0, rows = 0;
+    int max_rows = 0;
+    uint8_t *desc = nullptr;          // cap_rows x 32
+    float *pts3d = nullptr;           // cap_rows x 3
+    float *kp2d = nullptr;            // cap_rows x 2 (keypoints_2d; only kept for reloc_db_fetch)
+    int64_t *off = nullptr;           // cap_records + 1
+    double *pose = nullptr;           // cap_records x 7
+    double *xy_heading = nullptr;     // cap_records x 4
+    int32_t *counts = nullptr;        // cap_records
+    unsigned long long *topk_part = nullptr;
+    int topk_blocks = 0;
 };
 
 // Per-candidate PnP output
@@ -142,7 +166,6 @@ __device__ __forceinline__ bool heading_ok(const double *__restrict__ rec4, doub
 {
     return rec4[2] * cc + rec4[3] * sc > cos_tol;
 }
-__device__ __forceinline__ double heading_cos_tol() { return cos(RELOC_HEADING_TOL_DEG * 3.14159265358979323846 / 180.0); }
 
 // (cos, sin) of the robot's heading from the base_link quaternion (x, y, z, w)
 __device__ __forceinline__ void cur_heading_q(const double q[4], double &cc, double &sc)
@@ -159,6 +182,8 @@ __device__ __forceinline__ void cur_heading_q(const double q[4], double &cc, dou
 struct ScanMask {
     const double *xyh;
     double q[4];
+    double cos_tol = 6.123233995736766e-17;      // cos(HEADING_TOL_DEG = 90 degrees) in double
+    const int32_t *skip_if = nullptr;            // RELOC_TICK_AUTO: the whole launch stands down when *skip_if != 0
     // emit mode only (M:333-336): when g_obj is set, every mutual match also leaves its 3-D / 2-D pair
     // (keypoints_3d_cam[queryIdx], pts_curr_2d[trainIdx]) next to its index triplet, so no gather launch follows
     const float *g_pts3d = nullptr, *g_xy = nullptr;
@@ -211,17 +236,29 @@ struct reloc_ctx {
     double b2c_t[3] = {0.35, 0.0, 0.18};
     double b2c_R[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
 
-    // ---- database ----
+    // ---- matcher parameters (reloc_set_params) ----
+    reloc_params prm;
+    int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
+                                     // many workgroups, < 0 static default grid, 0 ticket scheduling
+    uint32_t *scan_ticket = nullptr; // 2 words: next record, workgroups that have left (k_db_scan ticket scheduling)
+
+    // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----
+    DbArena db_slot[2];
+    int db_sel = 0;
     int64_t db_records = 0, db_rows = 0;
+    int64_t db_cap_records = 0, db_cap_rows = 0;
     int db_max_rows = 0;
     uint8_t *db_desc = nullptr;
     float *db_pts3d = nullptr;
+    float *db_kp2d = nullptr;
     int64_t *db_off = nullptr;
     double *db_pose = nullptr;
     double *db_xy_heading = nullptr; // L x 4 (x, y, cos heading, sin heading) for candidate selection
     int32_t *db_counts = nullptr;    // L per-record mutual counts
     unsigned long long *topk_part = nullptr;   // per-block winners of the two-stage top-k (topk_blocks x 32)
     int topk_blocks = 0;
+    AccumResult *accum_res = nullptr;   // 1
+    int32_t *tick_flags = nullptr;      // [0] relocating flag of the current tick
 
     // ---- tick state ----
     int32_t *cand_ids = nullptr;     // MAX_CAND
@@ -247,6 +284,8 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
                    int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask = nullptr);
 int db_reindex(reloc_ctx *ctx);
+int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows);
+inline bool db_ready(const reloc_ctx *ctx) { return ctx->db_desc && ctx->db_off && ctx->db_pose && ctx->db_xy_heading && ctx->db_counts && ctx->db_records > 0; }
 int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures);
 int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,
                 int nfeatures);

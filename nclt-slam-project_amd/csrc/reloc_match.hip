@@ -27,11 +27,18 @@
 // order.  Keys are (distance << k | index): the minimum of packed keys is the smallest distance
 // with the LOWEST index on ties, which is the tie rule of the specification.
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "reloc_internal.h"
 
 typedef uint32_t u32;
 
+// RELOC_SCAN_PACKED (developer switch, nclt-slam-project_amd/build.py build_variant): 1 = two columns share one 32-bit
+// accumulator and the argmin bookkeeping runs on packed 16-bit halves (see scan_chunk); 0 = one 16-bit key per register.
+#ifndef RELOC_SCAN_PACKED
+#define RELOC_SCAN_PACKED 1
+#endif
 __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc)
 {
     u32 r;
@@ -49,6 +56,41 @@ __device__ __forceinline__ u32 shl7_u16(u32 a)
     u32 r;
     asm("v_lshlrev_b16 %0, 7, %1" : "=v"(r) : "v"(a));
     return r;
+}
+__device__ __forceinline__ u32 shl16(u32 a)
+{
+    u32 r;
+    asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
+// Packed bookkeeping of G (1 or 2) column pairs of one teach row.  p[g] = d(odd column) << 16 | d(even column);
+// key halves = d * 128 + (row-in-chunk * 8 + column slot) by ONE v_pk_mad_u16 (multiplier 0x00800080 in a VGPR, the
+// index pair in an SGPR); one v_pk_min_u16 keeps the best row of both columns (cb), another the best column of the row
+// (best, halves = even / odd slots).  All in one asm block: measured, tools/ubench_valu2.hip "scan pair" rows.
+template <int C0, int G, bool FIRST>
+__device__ __forceinline__ void packed_keys(const u32 (&p)[G], u32 kmul, u32 *cb, u32 &best)
+{
+    constexpr u32 c0 = (u32)(((C0 + 1) << 16) | C0), c1 = (u32)(((C0 + 3) << 16) | (C0 + 2));
+    if constexpr (G == 2) {
+        u32 k0, k1;
+        if constexpr (FIRST)
+            asm("v_pk_mad_u16 %0, %5, %7, %8\n\tv_pk_mad_u16 %1, %6, %7, %9\n\t"
+                "v_pk_min_u16 %2, %2, %0\n\tv_pk_min_u16 %3, %3, %1\n\tv_pk_min_u16 %4, %0, %1"
+                : "=&v"(k0), "=&v"(k1), "+v"(cb[0]), "+v"(cb[1]), "=v"(best) : "v"(p[0]), "v"(p[1]), "v"(kmul), "s"(c0), "s"(c1));
+        else
+            asm("v_pk_mad_u16 %0, %5, %7, %8\n\tv_pk_mad_u16 %1, %6, %7, %9\n\t"
+                "v_pk_min_u16 %2, %2, %0\n\tv_pk_min_u16 %3, %3, %1\n\tv_pk_min_u16 %0, %0, %1\n\tv_pk_min_u16 %4, %4, %0"
+                : "=&v"(k0), "=&v"(k1), "+v"(cb[0]), "+v"(cb[1]), "+v"(best) : "v"(p[0]), "v"(p[1]), "v"(kmul), "s"(c0), "s"(c1));
+    } else {
+        u32 k0;
+        if constexpr (FIRST)
+            asm("v_pk_mad_u16 %0, %3, %4, %5\n\tv_pk_min_u16 %1, %1, %0\n\tv_mov_b32 %2, %0"
+                : "=&v"(k0), "+v"(cb[0]), "=v"(best) : "v"(p[0]), "v"(kmul), "s"(c0));
+        else
+            asm("v_pk_mad_u16 %0, %3, %4, %5\n\tv_pk_min_u16 %1, %1, %0\n\tv_pk_min_u16 %2, %2, %0"
+                : "=&v"(k0), "+v"(cb[0]), "+v"(best) : "v"(p[0]), "v"(kmul), "s"(c0));
+    }
 }
 
 __device__ __forceinline__ u32 ham8(const u32 q[8], const uint4 a, const uint4 b, u32 init)
@@ -143,6 +185,12 @@ __device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
 }
 
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // One R-row chunk (R = 16 or 4) of a record against the wave's 64*NJ columns.
 //   q[j]    : descriptor of column colbase + j*64 + lane (padding columns repeat the last real column:
 //             a duplicate offers the same distance with a larger index, so it never wins a minimum)
@@ -155,20 +203,56 @@ template <int NJ, int R, bool CLAMP>
 __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[NJ][8],
                                            u32 colbase, u32 *rowkey, u32 *colbest, bool single_cb, int lane)
 {
+#if RELOC_SCAN_PACKED
+    constexpr int NP = NJ / 2;                       // packed registers: columns (2p, 2p + 1)
+    constexpr int G = NP >= 2 ? 2 : 1;               // registers per group: two distance chains are always interleaved
+    u32 cbp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) cbp[p] = 0xFFFFFFFFu;
+    u32 kmul = 0x00800080u;
+    asm volatile("" : "+v"(kmul));                   // stays in a VGPR: the index pair takes the one SGPR slot of v_pk_mad_u16
+#else
     u32 cb16[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
+#endif
     u32 rk[R];
     // Teach rows come through the scalar cache, one fetch in flight (see srow_landed).
     auto row_of = [&](int t) { return CLAMP ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
     uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
+    // compile-time row and column indices: the key constants are immediates
+    static_for<R>([&](auto tc_) {
+        constexpr int t = decltype(tc_)::value;
         srow_landed(a.x);                                                // row t is here ...
         uint4 na, nb;
         if (t + 1 < R) { na = rec[2 * row_of(t + 1)]; nb = rec[2 * row_of(t + 1) + 1]; }   // ... row t+1 on its way
         __builtin_amdgcn_sched_barrier(0);
         u32 best = 0;
+#if RELOC_SCAN_PACKED
+        const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        static_for<NP / G>([&](auto gc_) {
+            constexpr int p0 = G * decltype(gc_)::value;                 // first packed register of the group
+            u32 acc[G];
+            // odd columns first; their distance, moved to the high half, seeds the even column's chain
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = bcnt_acc(q[2 * (p0 + g) + 1][k] ^ w[k], acc[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = shl16(acc[g]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = bcnt_acc(q[2 * (p0 + g)][k] ^ w[k], acc[g]);
+            packed_keys<t * 8 + 2 * p0, G, p0 == 0>(acc, kmul, cbp + p0, best);
+        });
+        // best column of the row = smaller half; cross-lane key: best << 9 | lane = distance << 16 | t << 12 | slot << 9 | lane
+        asm("v_min_u16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+            "v_lshl_or_b32 %0, %0, 9, %2"
+            : "=&v"(rk[t]) : "v"(best), "v"(lane));
+#else
 #pragma unroll
         for (int j = 0; j < NJ; j += 2) {
             u32 h0, h1;
@@ -181,9 +265,10 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         // 32-bit cross-lane key: best << 9 | lane = distance << 16 | t << 12 | slot << 9 | lane.  The row bits
         // are equal across the lanes of one row, and (slot, lane) orders like the column slot * 64 + lane
         rk[t] = (best << 9) | (u32)lane;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < R) { a = na; b = nb; }
-    }
+    });
     const u32 m = rows_min<R>(rk, lane);
     const int row = tc + (lane & (R - 1));
     if (lane < R && row < n) {
@@ -193,7 +278,12 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const u32 key = ((cb16[j] >> 7) << 16) | (u32)(tc + (int)((cb16[j] >> 3) & 15u));
+#if RELOC_SCAN_PACKED
+        const u32 k16 = (j & 1) ? cbp[j >> 1] >> 16 : cbp[j >> 1] & 0xFFFFu;
+#else
+        const u32 k16 = cb16[j];
+#endif
+        const u32 key = ((k16 >> 7) << 16) | (u32)(tc + (int)((k16 >> 3) & 15u));
         atomicMin(&colbest[colbase + j * 64 + lane], key);
     }
 }
@@ -211,7 +301,7 @@ __device__ __forceinline__ void db_scan_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
     int32_t *__restrict__ counts, int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, const ScanMask &mask)
+    int32_t *__restrict__ m_n, int emit_stride, const ScanMask &mask, u32 *ticket)
 {
     constexpr int CB = 64 * NJ;           // columns per block
     const int tid = threadIdx.x, lane = tid & 63;
@@ -239,14 +329,39 @@ __device__ __forceinline__ void db_scan_body(
     double hc = 1.0, hs = 0.0, cos_tol = 0.0;
     if (mask.xyh) {
         cur_heading_q(mask.q, hc, hs);
-        cos_tol = heading_cos_tol();
+        cos_tol = mask.cos_tol;
     }
+    if (mask.skip_if && *mask.skip_if != 0) return;       // launch-uniform
 
-    for (int it = blockIdx.x; it < n_ids; it += gridDim.x) {
+    // Work distribution.  ticket == NULL: record it = blockIdx.x, + gridDim.x, ... (static).  Otherwise the grid is one
+    // resident generation and every workgroup draws its next record from a counter (ticket[0]); the draw for record
+    // k + 1 is in flight while record k is processed, so its latency is hidden.  The last workgroup to leave
+    // (ticket[1] counts them) puts both words back to zero for the next launch.
+    auto draw = [&]() -> u32 { return atomicAdd(&ticket[0], 1u); };
+    int it = blockIdx.x;
+    if (ticket) {
+        if (tid == 0) wsum[8] = draw();
+        __syncthreads();
+        it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
+    }
+    for (; it < n_ids;) {
+        u32 next_ticket = 0;
+        if (ticket && tid == 0) next_ticket = draw();
+        auto advance = [&]() {
+            if (ticket) {
+                __syncthreads();
+                if (tid == 0) wsum[8] = next_ticket;
+                __syncthreads();
+                it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
+            } else {
+                it += gridDim.x;
+            }
+        };
         const int r = rec_ids ? rec_ids[it] : it;
         if (mask.xyh && !heading_ok(mask.xyh + 4 * (int64_t)r, hc, hs, cos_tol)) {      // workgroup-uniform
             if (tid == 0 && counts) counts[EMIT ? it : r] = 0;
             if (EMIT && tid == 0 && m_n) m_n[it] = 0;
+            advance();
             continue;
         }
         const int64_t row0 = off[r];
@@ -315,6 +430,13 @@ __device__ __forceinline__ void db_scan_body(
             if (counts) counts[EMIT ? it : r] = (int32_t)base;
             if (EMIT && m_n) m_n[it] = (int32_t)base;
         }
+        advance();
+    }
+    if (ticket && tid == 0) {
+        if (atomicAdd(&ticket[1], 1u) == gridDim.x - 1) {      // every other workgroup has made its last draw
+            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -329,12 +451,12 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
     int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask)
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket)
 {
     extern __shared__ u32 lds[];
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
     db_scan_body<NJ, EMIT>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
-                           emit_stride, mask);
+                           emit_stride, mask, ticket);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -452,18 +574,23 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;
     const size_t lds = (size_t)(ncb * cb + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
-    // 4 generations of resident workgroups (4 per CU are resident): measured best on MI355X both for the
-    // stand-alone scan (finer load balance than one resident generation, 192 -> 175 us) and for several
-    // contexts sharing the chip (slots turn over, other streams' kernels get in: 1 / 2.5 / 4 / 6 generations
-    // give 4400 / 4750 / 4880 / 4825 frames/s in bench.py); beyond that the per-workgroup prologue (reload
-    // of the 500 current descriptors) costs more than the balance gains.
-    int grid = ctx->num_cu * 16;
-    if (const char *e = getenv("RELOC_SCAN_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // developer switch
+    // Whole-database scans (host-known record count, more records than resident workgroups) run ONE resident generation
+    // that draws records from a ticket counter: no tail of half-empty CUs while the last static generation drains, and
+    // the 16 KB-per-wave load of the current descriptors happens once per slot instead of once per workgroup of a
+    // 4-generation grid (r1: 16 workgroups per CU, records dealt round-robin; measured r2: profiles/r2_scan_variants.log).
+    // Everything else (candidate lists, single records) keeps the static round-robin loop.
+    const int resident = ctx->num_cu * 4;          // 4 workgroups of 4 waves per CU (128-VGPR kernel)
+    int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
+    u32 *ticket = nullptr;
+    if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0) {
+        ticket = ctx->scan_ticket;
+        grid = resident;
+    }
     if (grid > n_ids_max) grid = n_ids_max;
 #define RELOC_LAUNCH_SCAN(NJ, EMIT)                                                                                          \
     hipLaunchKernelGGL((k_db_scan<NJ, EMIT>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
-                       m_n, emit_stride, mask)
+                       m_n, emit_stride, mask, ticket)
     if (m_qidx) {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true); else RELOC_LAUNCH_SCAN(8, true);
     } else {
@@ -756,13 +883,17 @@ RELOC_API int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const
 }
 
 // ---- database ---------------------------------------------------------------------------------
-__global__ void k_db_index(const double *__restrict__ pose, int64_t n, double b0, double b1, double b2,
+// The selected database is a capacity-reserved arena (DbArena in reloc_internal.h): upload fills it, append copies one
+// record behind the last row, reserve grows it.  Nothing is published in the ctx before every allocation and copy of
+// an operation has succeeded: a failed upload leaves "no database" (db_records == 0), a failed reserve / append leaves
+// the database as it was.
+__global__ void k_db_index(const double *__restrict__ pose, int64_t first, int64_t n, double b0, double b1, double b2,
                            double *__restrict__ xyh)
 {
     // heading of base_link +X in the world from the stored CAMERA pose, exactly as the reference
     // composes it (M:233-245): R_wb = R_wc @ B.T, fwd = R_wb @ [1,0,0] = R_wc @ B[0,:]
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + n) return;
     const double qx = pose[7 * i + 3], qy = pose[7 * i + 4], qz = pose[7 * i + 5], qw = pose[7 * i + 6];
     const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
     const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
@@ -774,13 +905,110 @@ __global__ void k_db_index(const double *__restrict__ pose, int64_t n, double b0
     xyh[4 * i + 3] = fn > 0 ? fy / fn : 0.0;      // sin(heading)
 }
 
+// headings follow the camera mounting (reloc_set_camera); the (x, y) a record is filed under is kept
+__global__ void k_db_reheading(const double *__restrict__ pose, int64_t n, double b0, double b1, double b2, double *__restrict__ xyh)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double qx = pose[7 * i + 3], qy = pose[7 * i + 4], qz = pose[7 * i + 5], qw = pose[7 * i + 6];
+    const double r00 = 1 - 2 * (qy * qy + qz * qz), r01 = 2 * (qx * qy - qz * qw), r02 = 2 * (qx * qz + qy * qw);
+    const double r10 = 2 * (qx * qy + qz * qw), r11 = 1 - 2 * (qx * qx + qz * qz), r12 = 2 * (qy * qz - qx * qw);
+    const double fx = r00 * b0 + r01 * b1 + r02 * b2, fy = r10 * b0 + r11 * b1 + r12 * b2;
+    const double fn = sqrt(fx * fx + fy * fy);
+    xyh[4 * i + 2] = fn > 0 ? fx / fn : 1.0;
+    xyh[4 * i + 3] = fn > 0 ? fy / fn : 0.0;
+}
+
 int db_reindex(reloc_ctx *ctx)
 {
-    if (!ctx->db_pose || ctx->db_records <= 0) return RELOC_OK;
-    hipLaunchKernelGGL(k_db_index, dim3((unsigned)((ctx->db_records + 255) / 256)), dim3(256), 0, ctx->stream, ctx->db_pose,
-                       ctx->db_records, ctx->b2c_R[0], ctx->b2c_R[1], ctx->b2c_R[2], ctx->db_xy_heading);
+    // both resident databases follow a change of the camera mounting
+    for (int slot = 0; slot < 2; ++slot) {
+        const bool sel = slot == ctx->db_sel;
+        const double *pose = sel ? ctx->db_pose : ctx->db_slot[slot].pose;
+        double *xyh = sel ? ctx->db_xy_heading : ctx->db_slot[slot].xy_heading;
+        const int64_t n = sel ? ctx->db_records : ctx->db_slot[slot].records;
+        if (!pose || !xyh || n <= 0) continue;
+        hipLaunchKernelGGL(k_db_reheading, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pose, n, ctx->b2c_R[0],
+                           ctx->b2c_R[1], ctx->b2c_R[2], xyh);
+    }
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
+}
+
+namespace {
+struct DbBuffers {
+    uint8_t *desc = nullptr; float *pts3d = nullptr, *kp2d = nullptr; int64_t *off = nullptr; double *pose = nullptr, *xyh = nullptr;
+    int32_t *counts = nullptr; unsigned long long *topk = nullptr;
+    void release()
+    {
+        void *p[] = {desc, pts3d, kp2d, off, pose, xyh, counts, topk};
+        for (void *q : p) if (q) (void)hipFree(q);
+        *this = DbBuffers();
+    }
+};
+}   // namespace
+
+// Grow the selected arena to at least (cap_records, cap_rows); contents are kept.  All-or-nothing.
+int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
+{
+    if (cap_records < 1) cap_records = 1;
+    if (cap_rows < 1) cap_rows = 1;
+    if (cap_records <= ctx->db_cap_records && cap_rows <= ctx->db_cap_rows && ctx->db_desc) return RELOC_OK;
+    if (cap_records < ctx->db_cap_records) cap_records = ctx->db_cap_records;
+    if (cap_rows < ctx->db_cap_rows) cap_rows = ctx->db_cap_rows;
+    if (cap_records > MAX_DB_RECORDS) { reloc_set_error("database: more than %lld records", (long long)MAX_DB_RECORDS); return RELOC_E_CAPACITY; }
+    DbBuffers nb;
+    const int blocks = (int)((cap_records + 1023) / 1024);
+    hipError_t e = hipSuccess;
+    auto grab = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    grab((void **)&nb.desc, (size_t)cap_rows * 32);
+    grab((void **)&nb.pts3d, (size_t)cap_rows * 12);
+    grab((void **)&nb.kp2d, (size_t)cap_rows * 8);
+    grab((void **)&nb.off, (size_t)(cap_records + 1) * 8);
+    grab((void **)&nb.pose, (size_t)cap_records * 56);
+    grab((void **)&nb.xyh, (size_t)cap_records * 32);
+    grab((void **)&nb.counts, (size_t)cap_records * 4);
+    grab((void **)&nb.topk, (size_t)blocks * 32 * sizeof(unsigned long long));
+    const int64_t L = ctx->db_desc ? ctx->db_records : 0, T = ctx->db_desc ? ctx->db_rows : 0;
+    auto copy = [&](void *d, const void *s_, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    };
+    if (L > 0) {
+        copy(nb.desc, ctx->db_desc, (size_t)T * 32);
+        copy(nb.pts3d, ctx->db_pts3d, (size_t)T * 12);
+        copy(nb.kp2d, ctx->db_kp2d, (size_t)T * 8);
+        copy(nb.off, ctx->db_off, (size_t)(L + 1) * 8);
+        copy(nb.pose, ctx->db_pose, (size_t)L * 56);
+        copy(nb.xyh, ctx->db_xy_heading, (size_t)L * 32);
+    } else if (e == hipSuccess) {
+        e = hipMemsetAsync(nb.off, 0, 8, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        nb.release();
+        reloc_set_error("database reserve (%lld records, %lld rows) failed: %s", (long long)cap_records, (long long)cap_rows,
+                        hipGetErrorString(e));
+        return RELOC_E_HIP;
+    }
+    DbBuffers old;
+    old.desc = ctx->db_desc; old.pts3d = ctx->db_pts3d; old.kp2d = ctx->db_kp2d; old.off = ctx->db_off; old.pose = ctx->db_pose;
+    old.xyh = ctx->db_xy_heading; old.counts = ctx->db_counts; old.topk = ctx->topk_part;
+    ctx->db_desc = nb.desc; ctx->db_pts3d = nb.pts3d; ctx->db_kp2d = nb.kp2d; ctx->db_off = nb.off; ctx->db_pose = nb.pose;
+    ctx->db_xy_heading = nb.xyh; ctx->db_counts = nb.counts; ctx->topk_part = nb.topk;
+    ctx->topk_blocks = blocks;
+    ctx->db_cap_records = cap_records;
+    ctx->db_cap_rows = cap_rows;
+    ctx->db_records = L;
+    ctx->db_rows = T;
+    old.release();
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
+{
+    ARG_CHECK_CTX(ctx, cap_records >= 0 && cap_rows >= 0, "reloc_db_reserve");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return db_reserve(ctx, cap_records, cap_rows);
 }
 
 RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const int64_t *offsets,
@@ -798,31 +1026,115 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     }
     ARG_CHECK(T == 0 || (desc && pts3d), "desc / pts3d missing");
     ARG_CHECK(n_records == 0 || poses, "poses missing");
+    if (n_records > MAX_DB_RECORDS) { reloc_set_error("database: %lld records (max %lld)", (long long)n_records, (long long)MAX_DB_RECORDS); return RELOC_E_CAPACITY; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    void **olds[] = {(void **)&ctx->db_desc, (void **)&ctx->db_pts3d, (void **)&ctx->db_off, (void **)&ctx->db_pose,
-                     (void **)&ctx->db_xy_heading, (void **)&ctx->db_counts, (void **)&ctx->topk_part};
-    for (void **p : olds) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
-    HIP_TRY(hipMalloc((void **)&ctx->db_desc, (size_t)(T > 0 ? T : 1) * 32));
-    HIP_TRY(hipMalloc((void **)&ctx->db_pts3d, (size_t)(T > 0 ? T : 1) * 12));
-    HIP_TRY(hipMalloc((void **)&ctx->db_off, (size_t)(n_records + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&ctx->db_pose, (size_t)(n_records > 0 ? n_records : 1) * 56));
-    HIP_TRY(hipMalloc((void **)&ctx->db_xy_heading, (size_t)(n_records > 0 ? n_records : 1) * 32));
-    HIP_TRY(hipMalloc((void **)&ctx->db_counts, (size_t)(n_records > 0 ? n_records : 1) * 4));
-    ctx->topk_blocks = (int)((n_records + 1023) / 1024 > 0 ? (n_records + 1023) / 1024 : 1);
-    HIP_TRY(hipMalloc((void **)&ctx->topk_part, (size_t)ctx->topk_blocks * 32 * sizeof(unsigned long long)));
+    // from here on the ctx holds no database until everything below has succeeded
+    ctx->db_records = 0;
+    ctx->db_rows = 0;
+    ctx->db_max_rows = 0;
+    int rc = db_reserve(ctx, n_records, T);
+    if (rc) return rc;
     if (T > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_desc, desc, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->db_pts3d, pts3d, (size_t)T * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->db_kp2d, 0, (size_t)T * 8, ctx->stream));
     }
     HIP_TRY(hipMemcpyAsync(ctx->db_off, offsets, (size_t)(n_records + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (n_records > 0) {
         HIP_TRY(hipMemcpyAsync(ctx->db_pose, poses, (size_t)n_records * 56, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_db_index, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, ctx->db_pose, (int64_t)0,
+                           n_records, ctx->b2c_R[0], ctx->b2c_R[1], ctx->b2c_R[2], ctx->db_xy_heading);
+        HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->db_records = n_records;
     ctx->db_rows = T;
     ctx->db_max_rows = maxrows;
-    int rc = db_reindex(ctx);
+    return RELOC_OK;
+}
+
+// room for one more record of n rows; geometric growth when the reserve is exhausted
+static int db_make_room(reloc_ctx *ctx, int64_t n)
+{
+    if (ctx->db_desc && ctx->db_records + 1 <= ctx->db_cap_records && ctx->db_rows + n <= ctx->db_cap_rows) return RELOC_OK;
+    const int64_t need_r = ctx->db_records + 1, need_t = ctx->db_rows + n;
+    int64_t cr = ctx->db_cap_records + ctx->db_cap_records / 2 + 64, ct = ctx->db_cap_rows + ctx->db_cap_rows / 2 + 64 * 512;
+    if (cr < need_r) cr = need_r;
+    if (ct < need_t) ct = need_t;
+    if (cr > MAX_DB_RECORDS) cr = MAX_DB_RECORDS;
+    if (need_r > MAX_DB_RECORDS) { reloc_set_error("database: more than %lld records", (long long)MAX_DB_RECORDS); return RELOC_E_CAPACITY; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return db_reserve(ctx, cr, ct);
+}
+
+RELOC_API int reloc_db_append(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, const float *kp2d, int n,
+                              const double pose[7], const double index_xy[2])
+{
+    ARG_CHECK_CTX(ctx, n >= 0 && pose && (n == 0 || (desc && pts3d)), "reloc_db_append");
+    if (n > MAX_REC_ROWS) { reloc_set_error("record has %d rows (max %d)", n, MAX_REC_ROWS); return RELOC_E_CAPACITY; }
+    int rc = db_make_room(ctx, n);
     if (rc) return rc;
+    const int64_t L = ctx->db_records, T = ctx->db_rows;
+    if (n > 0) {
+        HIP_TRY(hipMemcpyAsync(ctx->db_desc + T * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->db_pts3d + T * 3, pts3d, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        if (kp2d) HIP_TRY(hipMemcpyAsync(ctx->db_kp2d + T * 2, kp2d, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        else HIP_TRY(hipMemsetAsync(ctx->db_kp2d + T * 2, 0, (size_t)n * 8, ctx->stream));
+    }
+    const int64_t end = T + n;
+    HIP_TRY(hipMemcpyAsync(ctx->db_off + L + 1, &end, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->db_pose + 7 * L, pose, 56, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_db_index, dim3(1), dim3(64), 0, ctx->stream, ctx->db_pose, L, (int64_t)1, ctx->b2c_R[0], ctx->b2c_R[1],
+                       ctx->b2c_R[2], ctx->db_xy_heading);
+    HIP_TRY(hipGetLastError());
+    if (index_xy) HIP_TRY(hipMemcpyAsync(ctx->db_xy_heading + 4 * L, index_xy, 16, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));     // the host sources may go away; the record is visible from here on
+    ctx->db_records = L + 1;
+    ctx->db_rows = end;
+    if (n > ctx->db_max_rows) ctx->db_max_rows = n;
+    return RELOC_OK;
+}
+
+static void db_store_slot(reloc_ctx *ctx)
+{
+    DbArena &a = ctx->db_slot[ctx->db_sel];
+    a.cap_records = ctx->db_cap_records; a.cap_rows = ctx->db_cap_rows; a.records = ctx->db_records; a.rows = ctx->db_rows;
+    a.max_rows = ctx->db_max_rows; a.desc = ctx->db_desc; a.pts3d = ctx->db_pts3d; a.kp2d = ctx->db_kp2d; a.off = ctx->db_off;
+    a.pose = ctx->db_pose; a.xy_heading = ctx->db_xy_heading; a.counts = ctx->db_counts; a.topk_part = ctx->topk_part;
+    a.topk_blocks = ctx->topk_blocks;
+}
+
+RELOC_API int reloc_db_select(reloc_ctx *ctx, int slot)
+{
+    ARG_CHECK_CTX(ctx, slot == 0 || slot == 1, "reloc_db_select: slot must be 0 or 1");
+    if (slot == ctx->db_sel) return RELOC_OK;
+    db_store_slot(ctx);
+    const DbArena &a = ctx->db_slot[slot];
+    ctx->db_sel = slot;
+    ctx->db_cap_records = a.cap_records; ctx->db_cap_rows = a.cap_rows; ctx->db_records = a.records; ctx->db_rows = a.rows;
+    ctx->db_max_rows = a.max_rows; ctx->db_desc = a.desc; ctx->db_pts3d = a.pts3d; ctx->db_kp2d = a.kp2d; ctx->db_off = a.off;
+    ctx->db_pose = a.pose; ctx->db_xy_heading = a.xy_heading; ctx->db_counts = a.counts; ctx->topk_part = a.topk_part;
+    ctx->topk_blocks = a.topk_blocks;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_db_fetch(reloc_ctx *ctx, int64_t record, uint8_t *desc, float *pts3d, float *kp2d, double pose[7],
+                             double index_xyh[4], int32_t *n)
+{
+    ARG_CHECK_CTX(ctx, record >= 0, "reloc_db_fetch");
+    if (!db_ready(ctx) || record >= ctx->db_records) { reloc_set_error("db fetch: record %lld of %lld", (long long)record, (long long)ctx->db_records); return RELOC_E_STATE; }
+    int64_t o[2];
+    HIP_TRY(hipMemcpyAsync(o, ctx->db_off + record, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t cnt = o[1] - o[0];
+    if (n) *n = (int32_t)cnt;
+    if (cnt > 0) {
+        if (desc) HIP_TRY(hipMemcpyAsync(desc, ctx->db_desc + o[0] * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (pts3d) HIP_TRY(hipMemcpyAsync(pts3d, ctx->db_pts3d + o[0] * 3, (size_t)cnt * 12, hipMemcpyDeviceToHost, ctx->stream));
+        if (kp2d) HIP_TRY(hipMemcpyAsync(kp2d, ctx->db_kp2d + o[0] * 2, (size_t)cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (pose) HIP_TRY(hipMemcpyAsync(pose, ctx->db_pose + 7 * record, 56, hipMemcpyDeviceToHost, ctx->stream));
+    if (index_xyh) HIP_TRY(hipMemcpyAsync(index_xyh, ctx->db_xy_heading + 4 * record, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RELOC_OK;
 }
@@ -834,7 +1146,7 @@ RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, 
                                         int32_t *counts_dev)
 {
     ARG_CHECK_CTX(ctx, cur_dev && counts_dev && n_cur_max >= 0, "reloc_db_match_counts_dev");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     int rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, cur_dev,
                             n_cur_dev, n_cur_max, ctx->db_max_rows, counts_dev, nullptr, nullptr, nullptr, nullptr, 0);
@@ -846,7 +1158,7 @@ RELOC_API int reloc_db_match_counts_dev(reloc_ctx *ctx, const uint8_t *cur_dev, 
 RELOC_API int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, double ratio, int32_t *counts)
 {
     ARG_CHECK_CTX(ctx, counts && n_cur >= 0 && (n_cur == 0 || cur) && ratio > 0, "reloc_db_ratio_counts");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
     if (n_cur > 65535) { reloc_set_error("ratio scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     void *dc;
@@ -866,7 +1178,7 @@ RELOC_API int reloc_db_ratio_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cu
 RELOC_API int reloc_db_match_counts(reloc_ctx *ctx, const uint8_t *cur, int n_cur, int32_t *counts)
 {
     ARG_CHECK_CTX(ctx, counts && n_cur >= 0 && (n_cur == 0 || cur), "reloc_db_match_counts");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (n_cur == 0) { memset(counts, 0, (size_t)ctx->db_records * 4); return RELOC_OK; }
     void *dc;
     int rc;

@@ -146,6 +146,205 @@ RELOC_API int reloc_record_frame(reloc_ctx *ctx, const uint8_t *img, const uint1
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Accumulation (reference M:435-500): after a tick that published nothing, the current frame becomes a new record when
+// the matcher has been silent long enough (host-side fact, silence_ok), no filed record lies within min_dist of the
+// robot and enough keypoints carry a usable depth.  The record is written straight behind the arena's last row; the
+// host adopts it (record / row counts) when it reads AccumResult.  NumPy dtype rules of the reference lines, as above:
+//   np.round(pts[:, 0]).astype(int32); (uu >= 1) & (uu < W - 1) & (vv >= 1) & (vv < H - 1)            M:449-453
+//   d_c = depth[vv, uu].astype(float32) / 1000.0; ok = (d_c > 0.5) & (d_c < 15.0)                     M:460-461
+//   (uu - cx) * d_c / fx in float64, stacked with z and cast to float32                                M:469-473
+//   camera pose = base pose (+) static mount, quaternion by scipy's Rotation.from_matrix().as_quat()   M:475-480
+struct AccumParams {
+    double fx, fy, cx, cy;
+    double base_pose[7], b2c_t[3], b2c_R[9];
+    double min_dist;
+    float zmin, zmax;
+    int w, h, min_kpts, silence_ok;
+    int64_t L, T;            // records / rows of the database before the append
+};
+
+// scipy.spatial.transform.Rotation.from_matrix (Markley's method) followed by as_quat(): x y z w, not canonicalised
+__device__ void rot_to_quat_scipy(const double R[9], double q[4])
+{
+    const double d0 = R[0], d1 = R[4], d2 = R[8], tr = R[0] + R[4] + R[8];
+    int choice = 0;
+    double best = d0;
+    if (d1 > best) { best = d1; choice = 1; }
+    if (d2 > best) { best = d2; choice = 2; }
+    if (tr > best) { best = tr; choice = 3; }
+    if (choice != 3) {
+        const int i = choice, j = (i + 1) % 3, k = (j + 1) % 3;
+        q[i] = 1 - tr + 2 * R[3 * i + i];
+        q[j] = R[3 * j + i] + R[3 * i + j];
+        q[k] = R[3 * k + i] + R[3 * i + k];
+        q[3] = R[3 * k + j] - R[3 * j + k];
+    } else {
+        q[0] = R[7] - R[5];
+        q[1] = R[2] - R[6];
+        q[2] = R[3] - R[1];
+        q[3] = 1 + tr;
+    }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int c = 0; c < 4; ++c) q[c] = q[c] / n;
+}
+
+__global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ f_xy, const uint8_t *__restrict__ f_desc,
+                                                     const int32_t *__restrict__ f_count, int max_feat,
+                                                     const uint16_t *__restrict__ depth, int dstride, AccumParams p,
+                                                     const TickResult *__restrict__ tick, double *__restrict__ xyh,
+                                                     uint8_t *__restrict__ db_desc, float *__restrict__ db_pts3d,
+                                                     float *__restrict__ db_kp2d, int64_t *__restrict__ db_off,
+                                                     double *__restrict__ db_pose, AccumResult *__restrict__ res)
+{
+    __shared__ int s_wsum[16];
+    __shared__ double s_wmin[16];
+    __shared__ int s_base;
+    __shared__ double s_near;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int oc = tick->outcome;
+    const bool wanted = p.silence_ok && (oc == RELOC_OUT_NO_CANDIDATES || oc == RELOC_OUT_NO_PNP_ACCEPT || oc == RELOC_OUT_CONSISTENCY_FAIL);
+    if (!wanted) {                                               // block-uniform
+        if (tid == 0) { res->appended = 0; res->n_kpts = 0; res->nearest_m = -1.0; }
+        return;
+    }
+    // nearest filed record (M:444-446)
+    double dmin = 1e300;
+    for (int64_t i = tid; i < p.L; i += 1024) {
+        const double dx = xyh[4 * i] - p.base_pose[0], dy = xyh[4 * i + 1] - p.base_pose[1];
+        dmin = fmin(dmin, sqrt(dx * dx + dy * dy));
+    }
+    for (int d = 32; d >= 1; d >>= 1) dmin = fmin(dmin, __shfl_xor(dmin, d));
+    if (lane == 0) s_wmin[wave] = dmin;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double m = s_wmin[0];
+        for (int w = 1; w < 16; ++w) m = fmin(m, s_wmin[w]);
+        s_near = m;
+    }
+    __syncthreads();
+    const double nearest = s_near;
+    if (nearest < p.min_dist) {
+        if (tid == 0) { res->appended = 0; res->n_kpts = 0; res->nearest_m = nearest; }
+        return;
+    }
+    const int n = min(*f_count, max_feat);
+    uint8_t *o_desc = db_desc + p.T * 32;
+    float *o_pts = db_pts3d + p.T * 3, *o_xy = db_kp2d + p.T * 2;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float x = 0, y = 0, dz = 0;
+        int u = 0, v = 0;
+        if (i < n) {
+            x = f_xy[2 * i]; y = f_xy[2 * i + 1];
+            u = (int)rintf(x); v = (int)rintf(y);
+            if (u >= 1 && u < p.w - 1 && v >= 1 && v < p.h - 1) {
+                dz = __fdiv_rn((float)depth[(size_t)v * dstride + u], 1000.0f);
+                keep = dz > p.zmin && dz < p.zmax;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += s_wsum[w];
+        if (keep) {
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            o_xy[2 * pos] = x; o_xy[2 * pos + 1] = y;
+            o_pts[3 * pos] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)u, p.cx), (double)dz), p.fx);
+            o_pts[3 * pos + 1] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)v, p.cy), (double)dz), p.fy);
+            o_pts[3 * pos + 2] = dz;
+            const uint4 *sp = reinterpret_cast<const uint4 *>(f_desc + (size_t)i * 32);
+            uint4 *dp = reinterpret_cast<uint4 *>(o_desc + (size_t)pos * 32);
+            dp[0] = sp[0]; dp[1] = sp[1];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int cnt = s_base;
+        res->n_kpts = cnt;
+        res->nearest_m = nearest;
+        if (cnt < p.min_kpts) { res->appended = 0; return; }
+        // camera pose from the base pose through the static mount (M:475-480)
+        double Rwb[9], Rwc[9], q[4];
+        quat_to_rot(p.base_pose[3], p.base_pose[4], p.base_pose[5], p.base_pose[6], Rwb);
+        double *pose = db_pose + 7 * p.L;
+        for (int r = 0; r < 3; ++r)
+            pose[r] = p.base_pose[r] + ((Rwb[3 * r] * p.b2c_t[0] + Rwb[3 * r + 1] * p.b2c_t[1]) + Rwb[3 * r + 2] * p.b2c_t[2]);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rwc[3 * r + c] = (Rwb[3 * r] * p.b2c_R[c] + Rwb[3 * r + 1] * p.b2c_R[3 + c]) + Rwb[3 * r + 2] * p.b2c_R[6 + c];
+        rot_to_quat_scipy(Rwc, q);
+        for (int c = 0; c < 4; ++c) pose[3 + c] = q[c];
+        // filed under the VIO position (M:491); heading as for every record (M:233-245, k_db_index)
+        double Rq[9];
+        quat_to_rot(q[0], q[1], q[2], q[3], Rq);
+        const double fx = Rq[0] * p.b2c_R[0] + Rq[1] * p.b2c_R[1] + Rq[2] * p.b2c_R[2];
+        const double fy = Rq[3] * p.b2c_R[0] + Rq[4] * p.b2c_R[1] + Rq[5] * p.b2c_R[2];
+        const double fn = sqrt(fx * fx + fy * fy);
+        xyh[4 * p.L] = p.base_pose[0];
+        xyh[4 * p.L + 1] = p.base_pose[1];
+        xyh[4 * p.L + 2] = fn > 0 ? fx / fn : 1.0;
+        xyh[4 * p.L + 3] = fn > 0 ? fy / fn : 0.0;
+        db_off[p.L + 1] = p.T + cnt;
+        res->appended = 1;
+    }
+}
+
+RELOC_API int reloc_tick_accumulate_dev(reloc_ctx *ctx, const uint16_t *depth_mm_dev, int w, int h, const double base_pose[7],
+                                        int silence_ok)
+{
+    ARG_CHECK_CTX(ctx, depth_mm_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_accumulate_dev");
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (ctx->db_records + 1 > ctx->db_cap_records || ctx->db_rows + ctx->max_feat > ctx->db_cap_rows) {
+        // grow first (drains the stream): the kernel writes behind the last row without asking
+        int rc = db_reserve(ctx, ctx->db_cap_records + ctx->db_cap_records / 2 + 64,
+                            ctx->db_cap_rows + ctx->db_cap_rows / 2 + 64 * (int64_t)ctx->max_feat);
+        if (rc) return rc;
+    }
+    AccumParams p;
+    p.fx = ctx->K4[0]; p.fy = ctx->K4[1]; p.cx = ctx->K4[2]; p.cy = ctx->K4[3];
+    for (int k = 0; k < 7; ++k) p.base_pose[k] = base_pose[k];
+    for (int k = 0; k < 3; ++k) p.b2c_t[k] = ctx->b2c_t[k];
+    for (int k = 0; k < 9; ++k) p.b2c_R[k] = ctx->b2c_R[k];
+    p.min_dist = ctx->prm.accum_min_dist_m;
+    p.zmin = (float)ctx->prm.accum_depth_min_m; p.zmax = (float)ctx->prm.accum_depth_max_m;
+    p.w = w; p.h = h; p.min_kpts = ctx->prm.accum_min_kpts; p.silence_ok = silence_ok;
+    p.L = ctx->db_records; p.T = ctx->db_rows;
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(1024), 0, ctx->stream, ctx->f_xy, ctx->f_desc, ctx->f_count, ctx->max_feat,
+                       depth_mm_dev, w, p, ctx->tick_res, ctx->db_xy_heading, ctx->db_desc, ctx->db_pts3d, ctx->db_kp2d, ctx->db_off,
+                       ctx->db_pose, ctx->accum_res);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_accumulate_result(reloc_ctx *ctx, int32_t *appended, int32_t *n_kpts, double *nearest_m)
+{
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
+    AccumResult r;
+    HIP_TRY(hipMemcpyAsync(&r, ctx->accum_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (r.appended == 1) {
+        // adopt the record the kernel wrote behind the last row; exactly once per accumulate call
+        ctx->db_records += 1;
+        ctx->db_rows += r.n_kpts;
+        if (r.n_kpts > ctx->db_max_rows) ctx->db_max_rows = r.n_kpts;
+        const int32_t zero = 0;
+        HIP_TRY(hipMemcpyAsync(&ctx->accum_res->appended, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (appended) *appended = r.appended;
+    if (n_kpts) *n_kpts = r.n_kpts;
+    if (nearest_m) *nearest_m = r.nearest_m;
+    return RELOC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Depth image -> obstacle point cloud (reference relay depth_cb,
 // tf_wall_clock_relay_v55.py:1020-1038): every `step`-th pixel, keep 0.3 < z < 10 and finite,
 // point = (z, -(u - cx) / fx * z, -(v - cy) / fy * z) in float32, raster order.

@@ -14,9 +14,12 @@ struct TickParams {
     double base_pose[7];
     double b2c_t[3];
     double b2c_R[9];
-    int global_reloc;
-    int check_consistency;
+    int mode;                 // RELOC_TICK_LOCAL / GLOBAL / AUTO; which one produced the candidates is the device flag
+    int check_consistency;    // 1 / 0, or -1: only when the candidates are local (M:391, G:424)
     int n_records;
+    // matcher parameters (reloc_params)
+    int max_candidates, min_matches, min_inliers, global_min_inliers;
+    double radius_m, cos_tol, reproj_max_px, global_reproj_max_px, consistency_m;
 };
 
 __device__ void rot_to_quat(const double R[9], double q[4])
@@ -164,10 +167,11 @@ struct LocalKey {
 
 struct CountKey {
     const int32_t *counts;
+    int min_matches;
     __device__ unsigned long long operator()(int i) const
     {
         const int c = counts[i];
-        return c < RELOC_MIN_MATCHES ? 0ull : ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
+        return c < min_matches ? 0ull : ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
     }
 };
 
@@ -199,36 +203,41 @@ __device__ int topk_final(KeyFn keyfn, int L, int k, const unsigned long long *p
 
 __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *__restrict__ xyh, TickParams prm,
                                                                  const unsigned long long *__restrict__ part, int n_blocks,
-                                                                 int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n)
+                                                                 int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n,
+                                                                 int32_t *__restrict__ relocating)
 {
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int L = prm.n_records;
     const double vx = prm.base_pose[0], vy = prm.base_pose[1];
-    const int n = topk_final(LocalKey{xyh, vx, vy}, L, min(RELOC_MAX_CANDIDATES * 3, L), part, n_blocks, s_red, s_keys);
+    const int n = topk_final(LocalKey{xyh, vx, vy}, L, min(prm.max_candidates * 3, L), part, n_blocks, s_red, s_keys);
     __syncthreads();
     if (threadIdx.x == 0) {
         double cc, sc;
         cur_heading(prm, cc, sc);
-        const double cos_tol = heading_cos_tol();
         int m = 0;
-        for (int r = 0; r < n && m < RELOC_MAX_CANDIDATES; ++r) {
+        for (int r = 0; r < n && m < prm.max_candidates; ++r) {
             const int i = 0xFFFFF - (int)(s_keys[r] & 0xFFFFF);
             const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
-            if (sqrt(dx * dx + dy * dy) < RELOC_CANDIDATE_RADIUS_M && heading_ok(xyh + 4 * i, cc, sc, cos_tol)) cand_ids[m++] = i;
+            if (sqrt(dx * dx + dy * dy) < prm.radius_m && heading_ok(xyh + 4 * i, cc, sc, prm.cos_tol)) cand_ids[m++] = i;
         }
         *cand_n = m;
+        *relocating = 0;
     }
 }
 
-__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base,
+// skip_if: RELOC_TICK_AUTO -- the local search found candidates (*skip_if != 0): they stand, nothing is ranked (the scan
+// before this kernel has skipped itself the same way).  relocating: set when the whole-database ranking produced the list.
+__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base, int min_matches,
                                                             const unsigned long long *__restrict__ part, int n_blocks,
                                                             int32_t *__restrict__ out_ids, int32_t *__restrict__ out_counts,
-                                                            int32_t *__restrict__ out_n)
+                                                            int32_t *__restrict__ out_n, const int32_t *skip_if,
+                                                            int32_t *__restrict__ relocating)
 {
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
-    const int n = topk_final(CountKey{counts}, L, k, part, n_blocks, s_red, s_keys);
+    if (skip_if && *skip_if != 0) return;                       // block-uniform; out_n (may alias skip_if) is written last
+    const int n = topk_final(CountKey{counts, min_matches}, L, k, part, n_blocks, s_red, s_keys);
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < k) {
@@ -240,30 +249,37 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__res
             if (out_counts) out_counts[tid] = 0;
         }
     }
-    if (tid == 0) *out_n = n;
+    if (tid == 0) {
+        *out_n = n;
+        if (relocating) *relocating = 1;
+    }
 }
 
 // host side of the two stages (one launch when the database is a single slice)
 static void launch_candidates_local(reloc_ctx *ctx, const TickParams &prm)
 {
-    const int L = prm.n_records, k = L < RELOC_MAX_CANDIDATES * 3 ? L : RELOC_MAX_CANDIDATES * 3;
+    const int L = prm.n_records, k = L < prm.max_candidates * 3 ? L : prm.max_candidates * 3;
     const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
     if (nb)
         hipLaunchKernelGGL(k_topk_part<LocalKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream,
                            LocalKey{ctx->db_xy_heading, prm.base_pose[0], prm.base_pose[1]}, L, k, ctx->topk_part);
     hipLaunchKernelGGL(k_candidates_local, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->topk_part, nb,
-                       ctx->cand_ids, ctx->cand_n);
+                       ctx->cand_ids, ctx->cand_n, ctx->tick_flags);
 }
 
-static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts)
+// auto_mode: the ranking only takes effect when the local search left no candidate (see k_topk_counts); the slice
+// kernel is harmless either way (it only writes topk_part)
+static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts, bool auto_mode)
 {
     const int L = (int)ctx->db_records;
     const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
+    const int mm = ctx->prm.min_matches;
     if (nb)
-        hipLaunchKernelGGL(k_topk_part<CountKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream, CountKey{ctx->db_counts}, L, k,
+        hipLaunchKernelGGL(k_topk_part<CountKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream, CountKey{ctx->db_counts, mm}, L, k,
                            ctx->topk_part);
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, ctx->topk_part, nb,
-                       out_ids, out_counts, ctx->cand_n);
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, mm, ctx->topk_part, nb,
+                       out_ids, out_counts, ctx->cand_n, auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr,
+                       ctx->tick_flags);
 }
 
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
@@ -272,17 +288,19 @@ static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t 
 __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
                                                       const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
                                                       const int32_t *__restrict__ f_count, TickParams prm,
-                                                      TickResult *__restrict__ res)
+                                                      const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res)
 {
     const int s = threadIdx.x;
     const int nc = min(*cand_n, MAX_CAND);
     const int nfeat = *f_count;
-    const int min_inl = prm.global_reloc ? 18 : RELOC_MIN_INLIERS;            // G:85
-    const double max_err = prm.global_reloc ? 1.5 : RELOC_REPROJ_MAX_PX;      // G:86
+    const int relocating = *relocating_p;
+    const int min_inl = relocating ? prm.global_min_inliers : prm.min_inliers;          // G:381
+    const double max_err = relocating ? prm.global_reproj_max_px : prm.reproj_max_px;   // G:382
+    const bool check = prm.check_consistency < 0 ? !relocating : prm.check_consistency != 0;
     bool okc = false;
     int inl = 0;
     double err = 0, pose[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (s < nc && nfeat >= RELOC_MIN_MATCHES) {
+    if (s < nc && nfeat >= prm.min_matches) {
         const PnpOut &p = pnp[s];
         if (p.ok && p.n_inl >= min_inl && !(p.reproj_mean > max_err)) {
             okc = true;
@@ -323,8 +341,8 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
         if (s == 0) {
             TickResult out;
             for (int k = 0; k < 7; ++k) out.anchor_pose[k] = 0;
-            out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.pad = 0; out.n_features = nfeat; out.n_candidates = nc;
-            out.outcome = nfeat < RELOC_MIN_MATCHES ? RELOC_OUT_NO_FEATURES : (nc == 0 ? RELOC_OUT_NO_CANDIDATES : RELOC_OUT_NO_PNP_ACCEPT);
+            out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.relocating = relocating; out.n_features = nfeat; out.n_candidates = nc;
+            out.outcome = nfeat < prm.min_matches ? RELOC_OUT_NO_FEATURES : (nc == 0 ? RELOC_OUT_NO_CANDIDATES : RELOC_OUT_NO_PNP_ACCEPT);
             *res = out;
         }
         return;
@@ -332,26 +350,35 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
     if (key == best) {
         TickResult out;
         for (int k = 0; k < 7; ++k) out.anchor_pose[k] = pose[k];
-        out.n_inl = inl; out.reproj = err; out.lm_idx = cand_ids[s]; out.pad = 0; out.n_features = nfeat; out.n_candidates = nc;
+        out.n_inl = inl; out.reproj = err; out.lm_idx = cand_ids[s]; out.relocating = relocating; out.n_features = nfeat; out.n_candidates = nc;
         const double dx = pose[0] - prm.base_pose[0], dy = pose[1] - prm.base_pose[1];
         const double shift = sqrt(dx * dx + dy * dy);
-        out.outcome = (prm.check_consistency && shift > RELOC_CONSISTENCY_M) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
+        out.outcome = (check && shift > prm.consistency_m) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
         *res = out;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-static TickParams make_tick_params(reloc_ctx *ctx, const double base_pose[7], int global_reloc, int check_consistency)
+static double heading_cos_tol_host(const reloc_ctx *ctx) { return cos(ctx->prm.heading_tol_deg * 3.14159265358979323846 / 180.0); }
+
+static TickParams make_tick_params(reloc_ctx *ctx, const double base_pose[7], int mode, int check_consistency)
 {
     TickParams p;
     for (int k = 0; k < 7; ++k) p.base_pose[k] = base_pose[k];
     for (int k = 0; k < 3; ++k) p.b2c_t[k] = ctx->b2c_t[k];
     for (int k = 0; k < 9; ++k) p.b2c_R[k] = ctx->b2c_R[k];
-    p.global_reloc = global_reloc;
+    p.mode = mode;
     p.check_consistency = check_consistency;
     p.n_records = (int)ctx->db_records;
+    const reloc_params &q = ctx->prm;
+    p.max_candidates = q.max_candidates; p.min_matches = q.min_matches; p.min_inliers = q.min_inliers;
+    p.global_min_inliers = q.global_min_inliers;
+    p.radius_m = q.candidate_radius_m; p.cos_tol = heading_cos_tol_host(ctx); p.reproj_max_px = q.reproj_max_px;
+    p.global_reproj_max_px = q.global_reproj_max_px; p.consistency_m = q.consistency_m;
     return p;
 }
+
+__global__ void k_set_flag(int32_t *flag, int v) { *flag = v; }
 
 static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
 {
@@ -366,11 +393,11 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
                              ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
                              ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit)))
         return rc;
-    if ((rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, RELOC_RANSAC_ITERATIONS, (float)RELOC_RANSAC_REPROJ_PX,
-                                 RELOC_RANSAC_CONFIDENCE, seed, RELOC_MIN_MATCHES)))
+    if ((rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, ctx->prm.ransac_iterations, (float)ctx->prm.ransac_reproj_px,
+                                 ctx->prm.ransac_confidence, seed, ctx->prm.min_matches)))
         return rc;
     hipLaunchKernelGGL(k_tick_finalize, dim3(1), dim3(64), 0, st, ctx->cand_ids, ctx->cand_n, ctx->p_out, ctx->db_pose,
-                       ctx->f_count, prm, ctx->tick_res);
+                       ctx->f_count, prm, ctx->tick_flags, ctx->tick_res);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
@@ -387,26 +414,29 @@ RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double 
 RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                              int global_reloc, uint64_t seed)
 {
-    ARG_CHECK_CTX(ctx, img_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_dev");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    ARG_CHECK_CTX(ctx, img_dev && base_pose && w >= 64 && h >= 64 && global_reloc >= 0 && global_reloc <= 2, "reloc_tick_dev");
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (ctx->max_feat > 65535) { reloc_set_error("tick: max_feat must be <= 65535"); return RELOC_E_CAPACITY; }
     int rc;
-    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
-    const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, !global_reloc);
-    if (global_reloc) {
-        // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others)
+    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
+    const int mode = global_reloc;
+    const TickParams prm = make_tick_params(ctx, base_pose, mode, -1);
+    if (mode != RELOC_TICK_GLOBAL) launch_candidates_local(ctx, prm);
+    if (mode != RELOC_TICK_LOCAL) {
+        // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others).  In AUTO
+        // mode the scan and the ranking stand down on the device when the local search has found candidates.
         ScanMask mask;
         mask.xyh = ctx->db_xy_heading;
         for (int k = 0; k < 4; ++k) mask.q[k] = base_pose[3 + k];
+        mask.cos_tol = prm.cos_tol;
+        mask.skip_if = mode == RELOC_TICK_AUTO ? ctx->cand_n : nullptr;
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                             ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
                             &mask);
         reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
         if (rc) return rc;
-        launch_topk_counts(ctx, RELOC_GLOBAL_MAX_CANDIDATES, ctx->cand_ids, nullptr);
-    } else {
-        launch_candidates_local(ctx, prm);
+        launch_topk_counts(ctx, ctx->prm.global_max_candidates, ctx->cand_ids, nullptr, mode == RELOC_TICK_AUTO);
     }
     return tick_solve(ctx, prm, seed);
 }
@@ -424,6 +454,24 @@ RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *
     if (lm_idx) *lm_idx = r.lm_idx;
     if (outcome) *outcome = r.outcome;
     if (n_candidates) *n_candidates = r.n_candidates;
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
+                                   int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating)
+{
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
+    TickResult r;
+    HIP_TRY(hipMemcpyAsync(&r, ctx->tick_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
+    if (n_inl) *n_inl = r.n_inl;
+    if (reproj) *reproj = r.reproj;
+    if (lm_idx) *lm_idx = r.lm_idx;
+    if (outcome) *outcome = r.outcome;
+    if (n_candidates) *n_candidates = r.n_candidates;
+    if (n_features) *n_features = r.n_features;
+    if (relocating) *relocating = r.relocating;
     return RELOC_OK;
 }
 
@@ -445,18 +493,19 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
 {
     ARG_CHECK_CTX(ctx, img_dev && topk_ids_dev && topk_counts_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64,
               "reloc_tick_scan_dev");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
-    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, 500))) return rc;
+    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
     ScanMask mask;
     mask.xyh = base_pose ? ctx->db_xy_heading : nullptr;
     for (int k = 0; k < 4; ++k) mask.q[k] = base_pose ? base_pose[3 + k] : (k == 3 ? 1.0 : 0.0);
+    mask.cos_tol = heading_cos_tol_host(ctx);
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                         ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0, &mask);
     reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
     if (rc) return rc;
-    launch_topk_counts(ctx, k, topk_ids_dev, topk_counts_dev);
+    launch_topk_counts(ctx, k, topk_ids_dev, topk_counts_dev, false);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
@@ -475,9 +524,12 @@ RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, 
                                    int check_consistency, uint64_t seed)
 {
     ARG_CHECK_CTX(ctx, cand_ids_dev && base_pose && n_cand >= 0 && n_cand <= MAX_CAND, "reloc_tick_solve_dev");
-    if (!ctx->db_desc || ctx->db_records <= 0) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     hipLaunchKernelGGL(k_set_candidates, dim3(1), dim3(64), 0, ctx->stream, cand_ids_dev, n_cand, ctx->cand_ids, ctx->cand_n);
-    const TickParams prm = make_tick_params(ctx, base_pose, !check_consistency, check_consistency);
+    // candidates of a sharded whole-database search carry the relocation gates unless the caller asks for the
+    // consistency check (= local candidates)
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, ctx->stream, ctx->tick_flags, check_consistency ? 0 : 1);
+    const TickParams prm = make_tick_params(ctx, base_pose, check_consistency ? RELOC_TICK_LOCAL : RELOC_TICK_GLOBAL, check_consistency);
     return tick_solve(ctx, prm, seed);
 }
 

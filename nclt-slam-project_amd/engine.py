@@ -63,6 +63,11 @@ class Engine:
         N.check(self._lib.reloc_h2d(self._ctx, C.c_void_p(dst_dev), N.ptr(src), src.nbytes), "reloc_h2d")
         self.sync()
 
+    def h2d_async(self, dst_dev: int, src: np.ndarray):
+        """enqueue only; `src` must stay alive and unchanged until the stream has passed the copy"""
+        assert src.flags["C_CONTIGUOUS"]
+        N.check(self._lib.reloc_h2d(self._ctx, C.c_void_p(dst_dev), N.ptr(src), src.nbytes), "reloc_h2d")
+
     def d2h(self, dst: np.ndarray, src_dev: int):
         assert dst.flags["C_CONTIGUOUS"]
         N.check(self._lib.reloc_d2h(self._ctx, N.ptr(dst), C.c_void_p(src_dev), dst.nbytes), "reloc_d2h")
@@ -173,6 +178,40 @@ class Engine:
         N.check(self._lib.reloc_db_upload(self._ctx, N.ptr(desc), N.ptr(pts3d), N.ptr(offsets), N.ptr(poses),
                                           len(poses)), "reloc_db_upload")
 
+    def db_reserve(self, cap_records: int, cap_rows: int):
+        """room for that many records / descriptor rows in the selected database without re-allocation"""
+        N.check(self._lib.reloc_db_reserve(self._ctx, int(cap_records), int(cap_rows)), "reloc_db_reserve")
+
+    def db_append(self, desc, pts3d, pose, keypoints_2d=None, index_xy=None):
+        """one more record behind the last (self.landmarks.append + index update, M:489-493)"""
+        desc = self._desc(desc, "db_append") if len(desc) else np.zeros((0, 32), np.uint8)
+        pts3d = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3)
+        if len(pts3d) != len(desc):
+            raise N.RelocError("db_append: descriptor / point counts differ")
+        kp = None if keypoints_2d is None else np.ascontiguousarray(keypoints_2d, np.float32).reshape(-1, 2)
+        if kp is not None and len(kp) != len(desc):
+            raise N.RelocError("db_append: descriptor / keypoint counts differ")
+        pose = np.ascontiguousarray(pose, np.float64).reshape(7)
+        ixy = None if index_xy is None else np.ascontiguousarray(index_xy, np.float64).reshape(2)
+        N.check(self._lib.reloc_db_append(self._ctx, N.ptr(desc), N.ptr(pts3d), N.ptr(kp), len(desc), N.ptr(pose), N.ptr(ixy)),
+                "reloc_db_append")
+
+    def db_select(self, slot: int):
+        """switch between the two resident databases (outbound / return leg, X:274-294)"""
+        N.check(self._lib.reloc_db_select(self._ctx, int(slot)), "reloc_db_select")
+
+    def db_fetch(self, record: int):
+        """one record back from the device: dict(pose, descriptors, keypoints_2d, keypoints_3d_cam, index_xyh)"""
+        n = C.c_int32()
+        N.check(self._lib.reloc_db_fetch(self._ctx, int(record), None, None, None, None, None, C.byref(n)), "reloc_db_fetch")
+        k = n.value
+        desc = np.empty((max(k, 1), 32), np.uint8); pts = np.empty((max(k, 1), 3), np.float32); kp = np.empty((max(k, 1), 2), np.float32)
+        pose = np.empty(7); xyh = np.empty(4)
+        N.check(self._lib.reloc_db_fetch(self._ctx, int(record), N.ptr(desc), N.ptr(pts), N.ptr(kp), N.ptr(pose), N.ptr(xyh),
+                                         C.byref(n)), "reloc_db_fetch")
+        return dict(pose=tuple(float(v) for v in pose), descriptors=desc[:k].copy(), keypoints_2d=kp[:k].copy(),
+                    keypoints_3d_cam=pts[:k].copy(), index_xyh=xyh, n_features=k)
+
     @property
     def db_records(self) -> int:
         return int(self._lib.reloc_db_records(self._ctx))
@@ -250,6 +289,30 @@ class Engine:
         return bool(ok.value), rvec, tvec, inl[: n.value].copy()
 
     # ------------------------------------------------------------------ fused tick
+    def get_params(self) -> "N.RelocParams":
+        p = N.RelocParams()
+        N.check(self._lib.reloc_get_params(self._ctx, C.byref(p)), "reloc_get_params")
+        return p
+
+    def set_params(self, **kw):
+        """matcher parameters of the fused tick (reloc_params in include/reloc.h); unnamed fields keep their value"""
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise N.RelocError(f"set_params: unknown parameter {k}")
+            setattr(p, k, v)
+        N.check(self._lib.reloc_set_params(self._ctx, C.byref(p)), "reloc_set_params")
+
+    def tick_accumulate_dev(self, depth_mm_dev: int, w: int, h: int, base_pose, silence_ok: bool):
+        bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
+        N.check(self._lib.reloc_tick_accumulate_dev(self._ctx, C.c_void_p(depth_mm_dev), w, h, N.ptr(bp), int(silence_ok)),
+                "reloc_tick_accumulate_dev")
+
+    def accumulate_result(self):
+        ap = C.c_int32(); n = C.c_int32(); d = C.c_double()
+        N.check(self._lib.reloc_accumulate_result(self._ctx, C.byref(ap), C.byref(n), C.byref(d)), "reloc_accumulate_result")
+        return dict(appended=bool(ap.value), n_kpts=n.value, nearest_m=d.value)
+
     def set_camera(self, K4=None, base_to_cam_t=None, base_to_cam_R=None):
         a = None if K4 is None else np.ascontiguousarray(K4, np.float64).reshape(4)
         b = None if base_to_cam_t is None else np.ascontiguousarray(base_to_cam_t, np.float64).reshape(3)
@@ -277,6 +340,7 @@ class Engine:
                     n_candidates=nc.value)
 
     def tick_dev(self, img_dev: int, w: int, h: int, base_pose, order_rgb=False, global_reloc=False, seed=0):
+        """global_reloc: False / True or a RELOC_TICK_* mode (2 = local first, whole-database search if that finds nothing)"""
         bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
         N.check(self._lib.reloc_tick_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
                                          int(global_reloc), int(seed)), "reloc_tick_dev")
@@ -317,8 +381,9 @@ class Engine:
         return self.tick_result()
 
     def tick_result(self):
-        anchor = np.zeros(7); n_inl = C.c_int32(); rep = C.c_float(); lm = C.c_int32(); oc = C.c_int32(); nc = C.c_int32()
-        N.check(self._lib.reloc_tick_result(self._ctx, N.ptr(anchor), C.byref(n_inl), C.byref(rep), C.byref(lm),
-                                            C.byref(oc), C.byref(nc)), "reloc_tick_result")
-        return dict(anchor_pose=anchor, n_inliers=n_inl.value, reproj=rep.value, lm_idx=lm.value, outcome=oc.value,
-                    n_candidates=nc.value)
+        anchor = np.zeros(7); n_inl = C.c_int32(); rep = C.c_double(); lm = C.c_int32(); oc = C.c_int32(); nc = C.c_int32()
+        nf = C.c_int32(); rl = C.c_int32()
+        N.check(self._lib.reloc_tick_result_ex(self._ctx, N.ptr(anchor), C.byref(n_inl), C.byref(rep), C.byref(lm),
+                                               C.byref(oc), C.byref(nc), C.byref(nf), C.byref(rl)), "reloc_tick_result_ex")
+        return dict(anchor_pose=anchor, n_inliers=n_inl.value, reproj=float(np.float32(rep.value)), lm_idx=lm.value,
+                    outcome=oc.value, n_candidates=nc.value, n_features=nf.value, relocating=bool(rl.value))

@@ -298,7 +298,7 @@ class LandmarkMatcherCore:
         pts3 = np.stack([(uu - cfg.cx) * z / cfg.fx, (vv - cfg.cy) * z / cfg.fy, z], axis=-1).astype(np.float32)
         R_wb = P.quat_to_rot(*base_pose[3:7])
         c = np.array(base_pose[:3], dtype=np.float64) + R_wb @ self.base_to_cam_t
-        q = P.rot_to_quat(R_wb @ self.base_to_cam_R)
+        q = P.rot_to_quat_scipy(R_wb @ self.base_to_cam_R)          # the reference converts with scipy here (M:478-479)
         rec = {"pose": (float(c[0]), float(c[1]), float(c[2]), *(float(v) for v in q)), "descriptors": dsc[ok],
                "keypoints_2d": p2[ok], "keypoints_3d_cam": pts3, "ts": ts, "n_features": int(len(pts3)),
                "accumulated": True}
@@ -310,22 +310,48 @@ class LandmarkMatcherCore:
 
 
 class FusedLandmarkMatcher:
-    """Same tick through ONE device call (reloc_tick): the landmark database lives in HBM, the host
-    uploads a frame and reads back the anchor.  Produces the same TickOutcome / CSV rows."""
+    """The whole repeat session through the fused device calls: both landmark databases live in HBM (outbound set and,
+    for the split variant X, the return-leg set), a tick uploads one frame (and the depth image when accumulation may
+    fire), the device runs candidate search -- local, and the whole-database search of variant G when that finds
+    nothing and G's silence / drift conditions hold (G:324-326) -- matching, PnP, gates, pose composition and the
+    accumulation of M:435-500, and the host reads back one result record.  Produces the same TickOutcome / CSV rows as
+    LandmarkMatcherCore and the reference node."""
 
-    def __init__(self, landmarks, log_csv=None, engine=None, config: MatcherConfig | None = None, seed: int = 0):
+    def __init__(self, landmarks, log_csv=None, engine=None, config: MatcherConfig | None = None, seed: int = 0,
+                 return_landmarks=None, swap_flag=None, logger=None):
         from .engine import Engine
-        self.cfg = config or MatcherConfig()
-        self.engine = engine or Engine()
+        self.cfg = cfg = config or MatcherConfig()
+        self.engine = e = engine or Engine()
+        self.log = logger or (lambda msg: None)
+        self.pkl_path = landmarks if isinstance(landmarks, str) else None
         data = load_landmarks(landmarks) if isinstance(landmarks, str) else landmarks
-        self.landmarks = data["landmarks"]
-        self.engine.set_camera([self.cfg.fx, self.cfg.fy, self.cfg.cx, self.cfg.cy],
-                               data.get("base_to_cam_translation", P.BASE_TO_CAM_TRANSLATION),
-                               data.get("base_to_cam_rot", P.BASE_TO_CAM_ROT))
-        self.engine.db_upload(*pack_landmarks(self.landmarks))
+        e.set_params(nfeatures=cfg.nfeatures, max_candidates=cfg.max_candidates, min_matches=cfg.min_matches,
+                     min_inliers=cfg.min_inliers, ransac_iterations=cfg.ransac_iterations,
+                     global_max_candidates=cfg.reloc_max_candidates, global_min_inliers=cfg.reloc_min_inliers,
+                     accum_min_kpts=cfg.accum_min_kpts, candidate_radius_m=cfg.candidate_radius_m,
+                     heading_tol_deg=cfg.heading_tol_deg, reproj_max_px=cfg.reproj_max_px,
+                     ransac_reproj_px=cfg.ransac_reproj_px, consistency_m=cfg.consistency_m,
+                     global_reproj_max_px=cfg.reloc_reproj_max_px, accum_min_dist_m=cfg.accum_min_dist_m)
+        e.set_camera([cfg.fx, cfg.fy, cfg.cx, cfg.cy], data.get("base_to_cam_translation", P.BASE_TO_CAM_TRANSLATION),
+                     data.get("base_to_cam_rot", P.BASE_TO_CAM_ROT))
+        self._return_src = return_landmarks
+        self.swap_flag = swap_flag
+        self._swapped = False
+        self._return_data = None
+        e.db_select(0)
+        if return_landmarks is not None:
+            # the return-leg set is resident from the start (slot 1); the swap is a pointer flip
+            self._return_data = load_landmarks(return_landmarks) if isinstance(return_landmarks, str) else return_landmarks
+            e.db_select(1)
+            self._upload(self._return_data["landmarks"])
+            e.db_select(0)
+        self._adopt(data)
+        self._upload(self.landmarks)
         self.seed = seed
         self.last_anchor_ts = 0.0
         self.n_attempts = self.n_published = 0
+        self._img_dev = self._depth_dev = 0
+        self._img_cap = self._depth_cap = 0
         self.log_csv = log_csv
         if log_csv:
             d = os.path.dirname(log_csv)
@@ -334,18 +360,100 @@ class FusedLandmarkMatcher:
             with open(log_csv, "w") as f:
                 f.write(CSV_HEADER)
 
-    def tick(self, bgr, base_pose, ts=None, global_reloc=False):
+    # ------------------------------------------------------------------ database
+    def _upload(self, landmarks):
+        e = self.engine
+        desc, pts, off, poses = pack_landmarks(landmarks)
+        # reserve for the accumulation of a session up front: appends then never re-allocate
+        e.db_reserve(len(poses) + 256, int(off[-1]) + 256 * self.cfg.nfeatures)
+        e.db_upload(desc, pts, off, poses)
+
+    def _adopt(self, data):
+        self.pkl_data = data
+        self.landmarks = data["landmarks"]
+        self.n_initial_landmarks = len(self.landmarks)
+        self.n_accumulated = 0
+
+    def maybe_swap_to_return(self):
+        """Variant X (X:274-294): once the flag file exists the return-leg set replaces the outbound one."""
+        if self._swapped or self._return_data is None or not self.swap_flag or not os.path.exists(self.swap_flag):
+            return False
+        self.engine.db_select(1)
+        if isinstance(self._return_src, str):
+            self.pkl_path = self._return_src
+        self._adopt(self._return_data)
+        self._swapped = True
+        self.log(f"[SWAP] return-leg landmarks selected ({len(self.landmarks)})")
+        return True
+
+    def save_augmented(self):
+        if self.n_accumulated > 0 and self.pkl_path:
+            out = self.pkl_path.replace(".pkl", "_augmented.pkl")
+            self.pkl_data["landmarks"] = self.landmarks
+            save_landmarks(out, self.pkl_data)
+            return out
+        return None
+
+    # ------------------------------------------------------------------ one attempt
+    def _stage(self, which, arr):
+        """device staging buffer of the frame / depth image, grown on demand; returns the device pointer"""
+        e = self.engine
+        ptr, cap = (self._img_dev, self._img_cap) if which == "img" else (self._depth_dev, self._depth_cap)
+        if cap < arr.nbytes:
+            if ptr:
+                e.dev_free(ptr)
+            ptr, cap = e.dev_alloc(arr.nbytes), arr.nbytes
+            if which == "img":
+                self._img_dev, self._img_cap = ptr, cap
+            else:
+                self._depth_dev, self._depth_cap = ptr, cap
+        e.h2d_async(ptr, arr)
+        return ptr
+
+    def tick(self, bgr, base_pose, ts=None, global_reloc=None, depth_mm=None, drift_est=0.0):
+        """One repeat attempt.  global_reloc: None = decide as the reference does (local candidates; the whole-database
+        search only under G's trigger, when cfg.global_reloc is set), True = whole-database search unconditionally
+        (benchmark shape), False = local only.  depth_mm enables accumulation (cfg.accum_enable)."""
+        cfg, e = self.cfg, self.engine
+        self.maybe_swap_to_return()
+        if bgr is None or base_pose is None:
+            return None
         ts = time.time() if ts is None else ts
         self.n_attempts += 1
-        r = self.engine.tick(bgr, base_pose, order_rgb=False, global_reloc=global_reloc, seed=self.seed)
+        if global_reloc is None:
+            trigger = cfg.global_reloc and (ts - self.last_anchor_ts) > cfg.reloc_age_s and drift_est > cfg.reloc_drift_m
+            mode = 2 if trigger else 0
+        else:
+            mode = 1 if global_reloc else 0
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        e.tick_dev(self._stage("img", bgr), w, h, base_pose, order_rgb=False, global_reloc=mode, seed=self.seed)
+        accumulate = cfg.accum_enable and depth_mm is not None
+        if accumulate:
+            depth_mm = np.ascontiguousarray(depth_mm, np.uint16)
+            if depth_mm.shape != (h, w):
+                raise ValueError("depth and colour sizes differ")
+            e.tick_accumulate_dev(self._stage("depth", depth_mm), w, h, base_pose,
+                                  silence_ok=not (ts - self.last_anchor_ts < cfg.accum_silence_s))
+        r = e.tick_result()
+        if accumulate:
+            acc = e.accumulate_result()
+            if acc["appended"]:
+                rec = e.db_fetch(e.db_records - 1)
+                rec.pop("index_xyh")
+                rec.update(ts=ts, accumulated=True)
+                self.landmarks.append(rec)
+                self.n_accumulated += 1
+                self.log(f"[ACCUM #{self.n_accumulated}] new landmark at ({base_pose[0]:.1f},{base_pose[1]:.1f})  "
+                         f"n_kpts={rec['n_features']}  nearest_existing={acc['nearest_m']:.1f}m")
         vio_xy = (base_pose[0], base_pose[1])
-        oc = r["outcome"]
+        oc, reloc = r["outcome"], r["relocating"]
         if oc == 1:
             o = TickOutcome(ts, vio_xy, r["n_candidates"], 0, None, None, "curr_no_features")
         elif oc == 2:
-            o = TickOutcome(ts, vio_xy, 0, 0, None, None, "no_candidates", relocating=global_reloc)
+            o = TickOutcome(ts, vio_xy, 0, 0, None, None, "no_candidates", relocating=reloc)
         elif oc == 3:
-            o = TickOutcome(ts, vio_xy, r["n_candidates"], 0, None, None, "no_pnp_accept", relocating=global_reloc)
+            o = TickOutcome(ts, vio_xy, r["n_candidates"], 0, None, None, "no_pnp_accept", relocating=reloc)
         else:
             anchor = tuple(float(v) for v in r["anchor_pose"])
             shift = math.hypot(anchor[0] - vio_xy[0], anchor[1] - vio_xy[1])
@@ -358,7 +466,7 @@ class FusedLandmarkMatcher:
                 self.last_anchor_ts = ts
                 o = TickOutcome(ts, vio_xy, r["n_candidates"], r["n_inliers"], r["reproj"], anchor,
                                 f"published_std{std:.2f}_shift{shift:.1f}", std=std, covariance=P.anchor_covariance(std),
-                                lm_idx=r["lm_idx"], relocating=global_reloc, published=True)
+                                lm_idx=r["lm_idx"], relocating=reloc, published=True)
         if self.log_csv:
             err = "" if o.reproj_err is None else f"{o.reproj_err:.2f}"
             ax = o.anchor_pose[0] if o.anchor_pose else ""

@@ -74,7 +74,8 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
             super().__init__("visual_landmark_matcher")
             cfg = MatcherConfig(global_reloc=global_reloc)
             if fused:
-                self.core = FusedLandmarkMatcher(pkl_path, log_csv, config=cfg)
+                self.core = FusedLandmarkMatcher(pkl_path, log_csv, config=cfg, return_landmarks=return_pkl,
+                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
             else:
                 self.core = LandmarkMatcherCore(pkl_path, log_csv, config=cfg, return_landmarks=return_pkl,
                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
@@ -86,8 +87,7 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
             signal.signal(signal.SIGTERM, self._sigterm)
 
         def _sigterm(self, *a):
-            if not fused:
-                self.core.save_augmented()
+            self.core.save_augmented()
             sys.exit(0)
 
         def _rgb_cb(self, msg):
@@ -109,7 +109,7 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
             if pose is None:
                 return
             if fused:
-                o = self.core.tick(self.last_rgb, pose)
+                o = self.core.tick(self.last_rgb, pose, depth_mm=self.last_depth, drift_est=read_drift())
             else:
                 o = self.core.tick(self.last_rgb, self.last_depth, pose, drift_est=read_drift())
             if o is None or not o.published:

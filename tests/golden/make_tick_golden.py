@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 REF_COMMON = "/root/reference/simulation/isaac/scripts/common"
 REF_G = "/root/reference/simulation/isaac/experiments/63_global_reloc/scripts/visual_landmark_matcher.py"
+REF_X = "/root/reference/simulation/isaac/experiments/69_repeat_road_split_landmarks_accel_noise/scripts/visual_landmark_matcher.py"
 OUT = os.path.join(HERE, "tick_scene.json")
 
 TEACH_X = [2.0, 4.5, 7.0, 9.5]
@@ -40,6 +41,15 @@ REPEAT = [(2.3, -0.2, -2.0), (4.6, 0.25, 3.0), (7.4, 0.1, 1.0), (9.0, -0.3, -1.5
           (3.0, 0.0, 170.0), (4.0, 9.5, 0.0), (4.5, 0.0, 60.0), (8.0, -1.0, -35.0), (9.5, 0.0, 80.0), (2.0, 5.0, -70.0),
           (2.5, 0.5, 75.0), (12.0, 4.0, 50.0)]
 GLOBAL = [(5.0, 9.0, 2.0), (6.0, -9.5, -3.0), (4.6, 0.25, 3.0)]   # first two: > 8 m from every record, only the whole-DB search can anchor
+# A repeat session that exercises accumulation (M:435-500): (x, y, yaw_deg, ts).  Off-route poses more than 5 m from
+# every record become new records once the matcher has been silent for 5 s; later ticks near them use those records.
+SESSION = [(2.3, -0.2, -2.0, 100.0), (5.0, 9.0, 2.0, 100.5), (5.0, 9.0, 2.0, 107.0), (5.3, 9.2, 4.0, 107.5),
+           (5.1, 8.8, 0.0, 108.0), (6.0, -9.5, -3.0, 108.5), (6.0, -9.5, -3.0, 120.0), (6.2, -9.3, -1.0, 120.5),
+           (7.4, 0.1, 1.0, 121.0), (5.0, 14.5, 0.0, 140.0), (5.2, 14.2, 3.0, 140.5)]
+# Split-landmark variant X: outbound = records 0-1, return = records 2-3; the flag file appears before tick X_SWAP_AT.
+XRUN = [(2.3, -0.2, -2.0), (4.6, 0.25, 3.0), (7.4, 0.1, 1.0), (9.0, -0.3, -1.5), (7.4, 0.1, 1.0), (9.0, -0.3, -1.5),
+        (2.3, -0.2, -2.0), (5.0, 9.0, 2.0), (5.2, 9.1, 1.0)]
+X_SWAP_AT = 4
 
 
 class _Published:
@@ -107,6 +117,40 @@ def load(path, name):
 
 def crc(a):
     return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def record_summary(lm, index_xy=None):
+    d = dict(n=int(lm["n_features"]), pose=[float(v) for v in lm["pose"]], desc_crc=crc(lm["descriptors"]),
+             kp2d_crc=crc(lm["keypoints_2d"]), kp3d_crc=crc(lm["keypoints_3d_cam"]), ts=float(lm["ts"]),
+             accumulated=bool(lm.get("accumulated", False)))
+    if index_xy is not None:
+        d["index_xy"] = [float(index_xy[0]), float(index_xy[1])]
+    return d
+
+
+def drive(mt, module, scene, ticks, fixed_ts, before_tick=None):
+    """feeds (x, y, yaw, ts) ticks to an unmodified reference matcher node; returns (csv rows, published, accumulated)"""
+    from nclt_slam_project_amd import synth
+    module.time.time = lambda: fixed_ts[0]
+    published = []
+    n_init = len(mt.landmarks)
+    for i, (x, y, yaw, ts) in enumerate(ticks):
+        if before_tick:
+            before_tick(i)
+        bp = synth.base_pose(x, y, yaw)
+        mt.last_rgb, mt.last_depth = scene.render(bp)
+        mt._read_pose = lambda bp=bp: bp
+        fixed_ts[0] = ts
+        n0 = len(mt.anchor_pub.msgs)
+        mt._tick()
+        if len(mt.anchor_pub.msgs) > n0:
+            msg = mt.anchor_pub.msgs[-1]
+            p, o = msg.pose.pose.position, msg.pose.pose.orientation
+            published.append(dict(tick=i, pose=[float(p.x), float(p.y), float(p.z), float(o.x), float(o.y), float(o.z), float(o.w)],
+                                  cov=[float(c) for c in msg.pose.covariance]))
+    rows = open(mt.log_csv).read().splitlines()
+    acc = [record_summary(lm, mt.xy[k]) for k, lm in enumerate(mt.landmarks) if lm.get("accumulated")]
+    return rows, published, acc, n_init
 
 
 def run(cv2_obj):
@@ -180,8 +224,34 @@ def run(cv2_obj):
             p, o = msg.pose.pose.position, msg.pose.pose.orientation
             published_g.append(dict(tick=i, pose=[float(p.x), float(p.y), float(p.z), float(o.x), float(o.y), float(o.z), float(o.w)]))
     rows_g = real_open(csv_g).read().splitlines()
+    accumulated_repeat = [record_summary(lm, mt.xy[k]) for k, lm in enumerate(mt.landmarks) if lm.get("accumulated")]
+    # ---- accumulation session with the unmodified matcher M
+    ms = M.VisualLandmarkMatcher(pkl, os.path.join(tmp, "out_s", "anchor_matches.csv"))
+    rows_s, pub_s, acc_s, _ = drive(ms, M, scene, SESSION, fixed_ts)
+    # ---- split-landmark variant X, unmodified: outbound / return files, swap flag appears mid-session
+    import pickle
+    X = load(REF_X, "ref_matcher_x")
+    with real_open(pkl, "rb") as f:
+        data = pickle.load(f)
+    pkl_out, pkl_ret = os.path.join(tmp, "db", "out.pkl"), os.path.join(tmp, "db", "ret.pkl")
+    for path, lms in ((pkl_out, data["landmarks"][:2]), (pkl_ret, data["landmarks"][2:])):
+        with real_open(path, "wb") as f:
+            pickle.dump({**data, "landmarks": lms}, f)
+    flag = os.path.join(tmp, "swap_flag.txt")
+    mx = X.VisualLandmarkMatcher(pkl_out, os.path.join(tmp, "out_x", "anchor_matches.csv"), return_pkl=pkl_ret, swap_flag=flag)
+
+    def before(i):
+        if i == X_SWAP_AT:
+            with real_open(flag, "w") as f:
+                f.write("1")
+
+    rows_x, pub_x, acc_x, _ = drive(mx, X, scene, [(x, y, yaw, 3000.0 + 6.0 * i) for i, (x, y, yaw) in enumerate(XRUN)],
+                                    fixed_ts, before)
     return dict(teach_x=TEACH_X, repeat=REPEAT, global_poses=GLOBAL, records=records, csv=rows, published=published,
-                csv_global=rows_g, published_global=published_g)
+                csv_global=rows_g, published_global=published_g, accumulated_repeat=accumulated_repeat,
+                session=SESSION, csv_session=rows_s, published_session=pub_s, accumulated_session=acc_s,
+                xrun=XRUN, x_swap_at=X_SWAP_AT, csv_x=rows_x, published_x=pub_x, accumulated_x=acc_x,
+                x_landmarks_after=len(mx.landmarks))
 
 
 def main():
@@ -194,6 +264,12 @@ def main():
         print("  ", r)
     for r in gold["csv_global"]:
         print(" G", r)
+    for r in gold["csv_session"]:
+        print(" S", r)
+    for r in gold["csv_x"]:
+        print(" X", r)
+    print("accumulated: repeat", len(gold["accumulated_repeat"]), "session", [(a["n"], a["index_xy"]) for a in gold["accumulated_session"]],
+          "x", [(a["n"], a["index_xy"]) for a in gold["accumulated_x"]])
     print("records:", [(r["x"], r["n"]) for r in gold["records"]])
 
 

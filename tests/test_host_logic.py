@@ -146,6 +146,84 @@ def test_reference_nodes_dropin(oracle, gold):
     assert fresh["csv"] == gold["csv"]
     assert fresh["csv_global"] == gold["csv_global"]
     assert fresh["records"] == gold["records"]
+    assert fresh["csv_session"] == gold["csv_session"] and fresh["accumulated_session"] == gold["accumulated_session"]
+    assert fresh["csv_x"] == gold["csv_x"] and fresh["accumulated_x"] == gold["accumulated_x"]
+
+
+def _check_accumulated(landmarks, xy, expected):
+    import zlib
+    got = [(k, lm) for k, lm in enumerate(landmarks) if lm.get("accumulated")]
+    assert len(got) == len(expected)
+    for (k, lm), g in zip(got, expected):
+        assert lm["n_features"] == g["n"] and lm["ts"] == g["ts"]
+        np.testing.assert_allclose(lm["pose"], g["pose"], rtol=0, atol=1e-15)        # scipy's quaternion, sign included
+        assert zlib.crc32(np.ascontiguousarray(lm["descriptors"]).tobytes()) == g["desc_crc"]
+        assert zlib.crc32(np.ascontiguousarray(lm["keypoints_2d"]).tobytes()) == g["kp2d_crc"]
+        assert zlib.crc32(np.ascontiguousarray(lm["keypoints_3d_cam"]).tobytes()) == g["kp3d_crc"]
+        if xy is not None:
+            np.testing.assert_array_equal(xy[k], g["index_xy"])
+
+
+def test_session_with_accumulation_reproduces_reference(oracle, gold, scene, tmp_path):
+    """A repeat session in which off-route frames become new records (M:435-500) and later ticks anchor on them: CSV
+    rows, published poses and the accumulated records (pose with the reference's scipy quaternion, descriptors, 2-D and
+    3-D keypoints) equal what the reference's unmodified matcher produced."""
+    from oracle_backend import oracle_cv2
+    cv2 = oracle_cv2()
+    rec = _teach(cv2, scene, gold)
+    csv = str(tmp_path / "s" / "anchor_matches.csv")
+    m = LandmarkMatcherCore(rec.database(), csv, cv2=cv2)
+    pubs = []
+    for i, (x, y, yaw, ts) in enumerate(gold["session"]):
+        bp = synth.base_pose(x, y, yaw)
+        bgr, dep = scene.render(bp)
+        o = m.tick(bgr, dep, bp, ts=ts)
+        if o.published:
+            pubs.append((i, o))
+    assert open(csv).read().splitlines() == gold["csv_session"]
+    assert [i for i, _ in pubs] == [p["tick"] for p in gold["published_session"]]
+    for (_, o), p in zip(pubs, gold["published_session"]):
+        np.testing.assert_allclose(o.anchor_pose, p["pose"], atol=1e-9)
+    assert len(gold["accumulated_session"]) >= 3
+    _check_accumulated(m.landmarks, m.xy, gold["accumulated_session"])
+
+
+def test_split_variant_swap_reproduces_reference(oracle, gold, scene, tmp_path):
+    """Variant X run unmodified (outbound records 0-1, return records 2-3, flag file appearing mid-session, X:274-294):
+    same rows before and after the swap, same accumulated records."""
+    from oracle_backend import oracle_cv2
+    cv2 = oracle_cv2()
+    data = _teach(cv2, scene, gold).database()
+    flag = tmp_path / "swap_flag.txt"
+    csv = str(tmp_path / "x" / "anchor_matches.csv")
+    m = LandmarkMatcherCore({**data, "landmarks": list(data["landmarks"][:2])}, csv, cv2=cv2,
+                            return_landmarks={**data, "landmarks": list(data["landmarks"][2:])}, swap_flag=str(flag))
+    for i, (x, y, yaw) in enumerate(gold["xrun"]):
+        if i == gold["x_swap_at"]:
+            flag.write_text("1")
+        bp = synth.base_pose(x, y, yaw)
+        bgr, dep = scene.render(bp)
+        m.tick(bgr, dep, bp, ts=3000.0 + 6.0 * i)
+    assert open(csv).read().splitlines() == gold["csv_x"]
+    assert len(m.landmarks) == gold["x_landmarks_after"]
+    _check_accumulated(m.landmarks, m.xy, gold["accumulated_x"])
+
+
+def test_rot_to_quat_scipy_is_scipys_conversion():
+    """M:478-479 converts the accumulated record's rotation with scipy; the product restates it (no scipy dependency)."""
+    SR = pytest.importorskip("scipy.spatial.transform").Rotation
+    rng = np.random.default_rng(11)
+    for i in range(3000):
+        q = rng.normal(size=4)
+        if i % 4 == 0:
+            q = np.round(q, 1)
+            if not q.any():
+                continue
+        q /= np.linalg.norm(q)
+        R = P.quat_to_rot(*q)
+        if i % 3 == 0:
+            R = R @ P.BASE_TO_CAM_ROT
+        np.testing.assert_array_equal(P.rot_to_quat_scipy(R), SR.from_matrix(R).as_quat())
 
 
 def test_matcher_swap_and_accumulate(oracle, gold, scene, tmp_path):
