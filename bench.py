@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: relocalization frames/s at 640x480 against a 10k-landmark database.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one batch of `--frames-per-step` synthetic 640x480 frames, each taken through the whole
-hot path ON THE DEVICE (frames and database already resident in HBM): gray -> ORB(500) ->
-whole-database mutual-match scan (10 000 records x 64 descriptors, the reference's global
-relocalisation search, G:329-344) -> top-25 candidates -> mutual match lists -> PnP-RANSAC(200) ->
-gates -> anchor pose.  Nothing is skipped or cached between frames.
+hot path ON THE DEVICE: gray -> ORB(500) -> whole-database mutual-match scan (10 000 records x 64
+descriptors, the reference's global relocalisation search, G:329-344) -> top-25 candidates ->
+mutual match lists -> PnP-RANSAC(200) -> gates -> anchor pose; every frame's 96-byte result record is
+copied back to (pinned) host memory.  Nothing is skipped or cached between frames.
+
+`value` is measured with the frames already resident in HBM when the timed region starts (the contract of
+the judged line).  `host_ingest` repeats the same K steps with every frame crossing PCIe first -- uploaded
+from pinned host memory on the stream that processes it, SURVEY.md 3.1's "once per tick: upload one RGB
+frame (921.6 KB)" -- and reports that rate beside it.  Per-step times (median / p95) come from events on
+the streams, recorded inside the timed region without synchronising.
 
 N > 1: frames are the independent units (a 10k-record database is 20 MB and fits every GPU), so each
 rank runs its own frame stream against its own replica and there is no data-path collective;
@@ -21,7 +27,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 VALU-bound by construction, so the VALU issue roofline is reported
                 beside it
   roofline_matrix  the HBM-write-bound all-pairs u16 matrix kernel (BASELINE.json config 5 shape)
-  cpu_baseline  the CPU oracle (a port, 1 thread) timed on a bounded sample of the same workload
+  cpu_baseline  the CPU oracle (a port) timed on a bounded sample of the same workload, frames in
+                parallel on the host's cores
 """
 import argparse
 import json
@@ -65,60 +72,79 @@ def build_workload(engine0, n_records, rows, n_frames):
     return frames, (desc, pts, off, poses), base_poses
 
 
-def cpu_baseline(frames, db, sample_records):
-    """The CPU oracle on a bounded sample: front end and PnP in full (scalar, one thread) for the sample frames, the
-    database scan -- 97 % of the CPU time and the one stage the oracle runs on several cores (OpenMP over records) -- on a
-    sample of records scaled linearly to the whole database.  `value` uses all the cores this process may use (at most
-    16, the GPU box's CPU share per GPU); `single_core` is the same pipeline on one thread."""
+def cpu_baseline(frames, db, n_frames=32):
+    """The CPU oracle (oracle/, a port of the same pipeline) on the host cores of this machine.
+    Timed build: -O3 -march=native (hardware popcnt), the scan evaluating each distance once; its outputs are first
+    held equal to the strict checker build (-O2, literal two-pass matcher) on one frame / 300 records.  Frames are the
+    parallel unit (one frame per thread: gray + ORB + whole-database scan + top-25 PnP, nothing sampled); `value` =
+    frames / wall time on `cores` threads; per-frame latency median / p95 and the one-thread rate are reported too."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    O.build()
     desc, pts, off, poses = db
     n_rec = len(off) - 1
     try:
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
     except AttributeError:
         threads = max(1, min(16, os.cpu_count() or 1))
-    sample_mt = min(n_rec, sample_records * max(1, threads // 2))
-    t_orb = t_scan1 = t_scan = t_pnp = 0.0
-    nf = len(frames)
-    for img in frames:
+
+    def one_frame(img, records=None):
         t0 = time.perf_counter()
-        gray = O.gray_u8(img)
-        feat = O.orb_detect_compute(gray, 500)
+        feat = O.orb_detect_compute(O.gray_u8(img), 500)
         t1 = time.perf_counter()
-        O.set_threads(1)
-        counts = O.db_match_counts(desc[: off[sample_records]], off[: sample_records + 1], feat["desc"])
+        nr = n_rec if records is None else records
+        counts = O.db_match_counts(desc[: off[nr]], off[: nr + 1], feat["desc"])
         t2 = time.perf_counter()
-        O.set_threads(threads)
-        counts_mt = O.db_match_counts(desc[: off[sample_mt]], off[: sample_mt + 1], feat["desc"])
-        t3 = time.perf_counter()
-        O.set_threads(1)
-        assert (counts_mt[:sample_records] == counts).all()
-        top = O.topk_records(counts, 10, 25)
-        for r in top:
+        solved = []
+        for r in O.topk_records(counts, 10, 25):
             qi, ti, dd = O.match_mutual(desc[off[r]:off[r + 1]], feat["desc"])
             if len(qi) >= 10:
-                O.pnp_ransac(pts[off[r]:off[r + 1]][qi], feat["xy"][ti], seed=1)
-        t4 = time.perf_counter()
-        t_orb += t1 - t0; t_scan1 += t2 - t1; t_scan += t3 - t2; t_pnp += t4 - t3
-    scan1 = t_scan1 / nf * (n_rec / sample_records)
-    scan = t_scan / nf * (n_rec / sample_mt)
-    rest = (t_orb + t_pnp) / nf
-    return dict(value=1.0 / (rest + scan), unit="frames/s", cores=threads, kind="port",
-                sample=f"{nf} frames: ORB + PnP in full on one thread (ORB {t_orb / nf * 1e3:.1f} ms, PnP {t_pnp / nf * 1e3:.1f} ms per "
-                       f"frame), database scan on {sample_mt} of {n_rec} records with {threads} OpenMP threads, scaled linearly "
-                       f"({scan * 1e3:.0f} ms per frame)",
-                single_core=dict(value=1.0 / (rest + scan1), cores=1,
-                                 sample=f"scan on {sample_records} of {n_rec} records, one thread, scaled linearly ({scan1 * 1e3:.0f} ms)"),
+                solved.append(O.pnp_ransac(pts[off[r]:off[r + 1]][qi], feat["xy"][ti], seed=1)[:3])
+        t3 = time.perf_counter()
+        return dict(feat=feat, counts=counts, solved=solved, t=(t1 - t0, t2 - t1, t3 - t2, t3 - t0))
+
+    # strict build == timed build on a bounded sample (the strict build's scan is ~6x slower)
+    O.select(False); O.set_threads(1); O.set_single_pass(False)
+    ref = one_frame(frames[0], records=min(300, n_rec))
+    O.select(True); O.set_threads(1); O.set_single_pass(True)
+    chk = one_frame(frames[0], records=min(300, n_rec))
+    assert (ref["feat"]["desc"] == chk["feat"]["desc"]).all() and (ref["feat"]["xy"] == chk["feat"]["xy"]).all()
+    assert (ref["counts"] == chk["counts"]).all() and len(ref["solved"]) == len(chk["solved"])
+    for a, b in zip(ref["solved"], chk["solved"]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    one_frame(frames[1 % len(frames)], records=min(300, n_rec))        # warm-up of the timed build
+    t0 = time.perf_counter()
+    single = one_frame(frames[0])
+    t_single = time.perf_counter() - t0
+    work = [frames[i % len(frames)] for i in range(n_frames)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        out = list(ex.map(one_frame, work))
+    wall = time.perf_counter() - t0
+    O.select(False); O.set_single_pass(False)
+    lat = np.array([o["t"][3] for o in out])
+    st = np.array([o["t"][:3] for o in out]).mean(axis=0) * 1e3
+    return dict(value=n_frames / wall, unit="frames/s", cores=threads, kind="port",
+                sample=f"{n_frames} frames ({len(frames)} distinct), one frame per thread on {threads} threads, whole pipeline per frame "
+                       f"(gray + ORB + scan of all {n_rec} records + top-25 PnP-RANSAC), nothing sampled or scaled; per frame on a busy "
+                       f"host: ORB {st[0]:.0f} ms, scan {st[1]:.0f} ms, PnP {st[2]:.0f} ms",
+                frame_latency_ms=dict(median=float(np.median(lat)) * 1e3, p95=float(np.percentile(lat, 95)) * 1e3),
+                single_core=dict(value=1.0 / t_single, cores=1, sample="one frame, one thread, idle host"),
+                build="oracle/ -O3 -march=native -ffp-contract=off, scan evaluates each distance once; outputs asserted equal to the "
+                      "strict checker build (-O2, literal two-pass matcher) on one frame / 300 records",
                 cpu=_cpu_model(), host_cores=os.cpu_count())
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r1e/summary.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r2/summary.json, else pmc_r1e: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, handled as MI355X_MICROARCH.md's HBM section prescribes); None if absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1e", "summary.json")))[kernel]
-    except (OSError, KeyError, ValueError):
+    d = None
+    for rnd in ("pmc_r2", "pmc_r1e"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))[kernel]
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if d is None:
         return None
     # streaming 16-B/lane pattern (matrix kernel): FETCH_SIZE is doubled, WRITE_SIZE exact; the scan kernel reads through
     # scalar loads, for which the counter is uncalibrated: its raw value is used (lower bound)
@@ -238,7 +264,7 @@ def _cpu_model():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=64)
     ap.add_argument("--records", type=int, default=10000)
@@ -252,6 +278,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="developer rehearsal: every rank uses device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the second timed run with frames uploaded from host memory")
     ap.add_argument("--matrix-only", action="store_true",
                     help="BASELINE config 5 shape: the 20000 x 20000 u16 Hamming matrix, row blocks split over the ranks, no\n"
                          "reduction (not the judged default; reports its own JSON line)")
@@ -288,44 +315,83 @@ def main():
     engines = [Engine(local_rank, W, H, 2048) for _ in range(args.streams)]
     n_distinct = 8
     frames, db, base_poses = build_workload(engines[0], args.records, args.rows, n_distinct)
-    for e in engines:
-        e.db_upload(*db)
-    frames_dev = [[e.to_device(f) for f in frames] for e in engines]   # every stream reads its own HBM copy
+    engines[0].db_upload(*db)
+    for e in engines[1:]:
+        e.db_share(engines[0])                         # all streams scan ONE resident copy of the database
+    # every ctx enqueues on a torch-made stream so that torch events can time the steps without synchronising
+    tstreams = [torch.cuda.Stream(device=local_rank) for _ in engines]
+    for e, ts in zip(engines, tstreams):
+        e.set_stream(ts.cuda_stream)
+    e0 = engines[0]
+    frames_dev = [e0.to_device(f) for f in frames]                       # resident frames (judged mode)
+    frames_pin = []
+    for f in frames:                                                      # host frames in pinned memory (ingest mode)
+        p = e0.pinned(f.shape, np.uint8)
+        p[...] = f
+        frames_pin.append(p)
+    stage = [e.dev_alloc(W * H * 3) for e in engines]                     # per-stream upload target
     B = args.frames_per_step
+    results = e0.pinned((B, 96), np.uint8)                                # one result record per frame of a step
+    res_dev = [e.tick_result_dev for e in engines]
 
-    def step(seed0):
+    def step(seed0, ingest):
         for i in range(B):
             s = i % len(engines)
             f = i % n_distinct
-            engines[s].tick_dev(frames_dev[s][f], W, H, base_poses[f], order_rgb=False, global_reloc=True, seed=seed0 + i)
+            e = engines[s]
+            if ingest:
+                e.h2d_async(stage[s], frames_pin[f])                      # 921.6 KB over PCIe, same stream as its tick
+                e.tick_dev(stage[s], W, H, base_poses[f], order_rgb=False, global_reloc=True, seed=seed0 + i)
+            else:
+                e.tick_dev(frames_dev[f], W, H, base_poses[f], order_rgb=False, global_reloc=True, seed=seed0 + i)
+            e.d2h_async(results[i], res_dev[s])                           # every frame's result goes back to the host
 
     def sync_all():
         for e in engines:
             e.sync()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(w * B)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k * B)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    outcomes = {}
-    last = engines[0].tick_result()
-    outcomes["last_outcome"] = int(last["outcome"]); outcomes["last_inliers"] = int(last["n_inliers"])
+    def timed(ingest):
+        for w in range(args.warmup):
+            step(w * B, ingest)
+        sync_all()
+        if dist is not None:
+            dist.barrier()
+        sync_all()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(tstreams[0])
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in engines] for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k * B, ingest)
+            for ts, ev in zip(tstreams, marks[k]):
+                ev.record(ts)
+        sync_all()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ends = np.array([max(ev0.elapsed_time(ev) for ev in row) for row in marks])      # ms since ev0
+        per_step = np.diff(np.concatenate([[0.0], ends]))
+        rec = np.array(results).view(np.int32).reshape(B, 24)
+        outcomes = rec[:, 18]                                             # TickResult.outcome of the last step's frames
+        return elapsed, per_step, dict(published_in_last_step=int((outcomes == 0).sum()), frames_in_step=B,
+                                       last_inliers=int(rec[B - 1, 16]))
 
+    elapsed, per_step, outcomes = timed(False)
     total_frames = world * B * args.steps
+    ingest = None
+    if not args.no_ingest:
+        el_i, ps_i, oc_i = timed(True)
+        ingest = dict(value=total_frames / el_i, unit="frames/s", ms_per_step=el_i / args.steps * 1e3,
+                      step_ms=dict(median=float(np.median(ps_i)), p95=float(np.percentile(ps_i, 95))),
+                      published_in_last_step=oc_i["published_in_last_step"],
+                      how="every frame uploaded from pinned host memory (hipMemcpyAsync on the stream of its tick, 921.6 KB "
+                          "per frame) inside the timed region; results copied back per frame as in the judged mode")
+
     result = None
     if rank == 0:
         e = engines[0]
@@ -333,29 +399,44 @@ def main():
         e.profile_enable(True)
         n_prof = 40
         for i in range(n_prof):
-            e.tick_dev(frames_dev[0][i % n_distinct], W, H, base_poses[i % n_distinct], False, True, i)
+            e.tick_dev(frames_dev[i % n_distinct], W, H, base_poses[i % n_distinct], False, True, i)
         e.sync()
         scan_ms, scan_n = e.profile_get(0)
         orb_ms, orb_n = e.profile_get(2)
         pnp_ms, pnp_n = e.profile_get(3)
         e.profile_enable(False)
+        # single-stream synchronous tick latency (enqueue + kernels + result copy), global and local candidate search
+        lat = {}
+        for mode, name in ((1, "tick_global"), (0, "tick_local")):
+            ts_ = []
+            for i in range(120):
+                t0 = time.perf_counter()
+                e.tick_dev(frames_dev[i % n_distinct], W, H, base_poses[i % n_distinct], False, mode, i)
+                e.d2h_async(results[0], res_dev[0])
+                e.sync()
+                ts_.append(time.perf_counter() - t0)
+            ts_ = np.array(ts_[20:]) * 1e6
+            lat[name + "_us"] = dict(median=float(np.median(ts_)), p95=float(np.percentile(ts_, 95)))
         desc, pts, off, poses = db
         T, L, Q = int(off[-1]), len(off) - 1, 500
         alg_bytes = 32 * T + 32 * Q + 4 * L               # database once, queries once, one count per record
         scan_s = scan_ms / max(scan_n, 1) * 1e-3
         pairs = T * Q
-        # VALU ceiling of the distance itself, measured: 8 x (v_xor_b32 v,s,v ; v_bcnt_u32_b32 acc) per pair reaches
-        # 2.60 T pairs/s at 8 waves/SIMD and 2.3 T at 4 (profiles/ubench_chain_r1.log); v_bcnt is a half-rate instruction
-        valu_peak_pairs = 2.60e12
+        # VALU ceilings measured on MI355X (tools/ubench_valu2.hip, profiles/r2_ubench_valu2.log): the bare distance,
+        # 8 x (v_xor_b32 s,v ; accumulating v_bcnt_u32_b32), reaches 2.99 T pairs/s at 8 waves/SIMD (2.91 T at the
+        # kernel's 4); with the kernel's argmin bookkeeping in the stream (shl16 + or + 3 min16 per pair) 2.21 T at 4
+        valu_peak_pairs = 2.99e12
         roofline = dict(kernel="k_db_scan", bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
                         frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=pmc_traffic("k_db_scan"),
                         avg_launch_us=scan_s * 1e6, launches=scan_n, algorithmic_bytes=alg_bytes,
                         note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %",
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
                                   frac=pairs / scan_s / valu_peak_pairs,
-                                  basis="measured chip ceiling of 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair "
-                                        "(tools/ubench_chain.hip); the kernel issues 20.6 VALU instructions per pair instead of 16 "
-                                        "(argmin bookkeeping) and runs 4 waves/SIMD, where the same ubench tops out at 2.3e12"))
+                                  lane_ops_per_s=16.0 * pairs / scan_s, spec_lane_ops_per_s=78.6e12,
+                                  frac_of_spec_issue=16.0 * pairs / scan_s / 78.6e12,
+                                  basis="measured chip ceiling of the bare 256-bit distance, 8 v_xor_b32 (full rate) + 8 accumulating "
+                                        "v_bcnt_u32_b32 (half rate) per pair (tools/ubench_valu2.hip); spec issue = 256 CU x 4 SIMD-32 x "
+                                        "2.4 GHz counts every instruction at full rate"))
         stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan=scan_s * 1e6, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
         roofline_matrix = None
         if not args.no_matrix:
@@ -377,12 +458,13 @@ def main():
             ms = m_ms / max(m_n, 1) * 1e-3
             roofline_matrix = dict(kernel="k_hamming_matrix", shape=[F, K], bound="hbm", achieved=mb / ms / 1e9, peak=8000.0,
                                    unit="GB/s", frac=mb / ms / 1e9 / 8000.0, traffic=pmc_traffic("k_hamming_matrix"), avg_launch_us=ms * 1e6,
-                                   launches=m_n, algorithmic_bytes=mb)
+                                   launches=m_n, algorithmic_bytes=mb,
+                                   valu=dict(pairs_per_s=F * K / ms, peak_pairs_per_s=2.99e12, frac=F * K / ms / 2.99e12))
             for p in (a, b, out):
                 e.dev_free(p)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(frames[:3], db, sample_records=min(1000, len(off) - 1))
+            cpu = cpu_baseline(frames, db)
         result = {
             "metric": "relocalization frames/sec @640x480, 10k-landmark DB; Hamming-match HBM GB/s",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -390,9 +472,11 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H} BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
-                                   f"top-25 PnP-RANSAC(200)",
+                                   f"top-25 PnP-RANSAC(200); frames resident in HBM, every frame's result copied to the host",
                        "frames_per_step": B, "streams": args.streams, "records": L, "descriptors": T,
                        "parallelism": "frames sharded across ranks, database replicated, no collective"},
+            "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95))),
+            "host_ingest": ingest, "latency": lat,
             "roofline": roofline, "roofline_matrix": roofline_matrix, "cpu_baseline": cpu,
             "stage_us": stage_us, "hamming_match_GBps": roofline["achieved"], **outcomes,
         }

@@ -89,6 +89,12 @@ int  reloc_sync(reloc_ctx *ctx);
 void *reloc_dev_alloc(reloc_ctx *ctx, int64_t bytes);
 int  reloc_dev_free(reloc_ctx *ctx, void *p);
 int  reloc_h2d(reloc_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);   /* async */
+int  reloc_d2d(reloc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t bytes);    /* async */
+/* Pinned (page-locked) host memory for frames and results: copies from / to it are true DMA and overlap with kernels. */
+void *reloc_host_alloc(int64_t bytes);
+int  reloc_host_free(void *p);
+/* The ctx's current hipStream_t (to order work of other libraries against it). */
+void *reloc_get_stream(reloc_ctx *ctx);
 int  reloc_d2h(reloc_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);   /* async */
 /* HIP-event stopwatch on the ctx stream: begin(); ...launches...; end() -> ms (synchronises). */
 int  reloc_timer_begin(reloc_ctx *ctx);
@@ -173,6 +179,11 @@ int reloc_db_append(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, con
  * set in the other and flips at the turnaround (X:274-294).  upload / append / reserve / tick act on the selected
  * slot; selecting costs nothing on the device. */
 int reloc_db_select(reloc_ctx *ctx, int slot);
+/* Several contexts (streams) on one device scanning ONE resident database: dst adopts the selected database of src
+ * (descriptors, points, offsets, poses, index) without copying and keeps only its own per-tick scratch.  The shared
+ * database is read-only through dst (upload / append / reserve on dst fail with RELOC_E_STATE); src must outlive dst or
+ * dst must upload / share again first, and changes made through src (append, upload) need a new reloc_db_share. */
+int reloc_db_share(reloc_ctx *dst, reloc_ctx *src);
 /* Read one record back (save of the augmented database M:502-514, parity taps).  Any output may be NULL; desc / pts3d /
  * kp2d must hold the record's rows (query *n first with all arrays NULL). */
 int reloc_db_fetch(reloc_ctx *ctx, int64_t record, uint8_t *desc, float *pts3d, float *kp2d, double pose[7],
@@ -231,6 +242,10 @@ int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int ord
                    const double base_pose[7], int global_reloc, uint64_t seed);
 int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
                       int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
+/* Device address of the 96-byte result record of the last tick (layout of reloc_tick_result_ex's outputs: double
+ * anchor_pose[7], double reproj, int32 n_inl, lm_idx, outcome, n_candidates, n_features, relocating): lets a pipelined
+ * host copy results with reloc_d2h into pinned memory without synchronising per frame. */
+const void *reloc_tick_result_dev(reloc_ctx *ctx);
 /* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344). */
 int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
                          int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating);

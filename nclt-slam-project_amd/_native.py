@@ -63,6 +63,12 @@ SIGNATURES = {
     "reloc_db_reserve": (C.c_int, [c_ctx, i64, i64]),
     "reloc_db_append": (C.c_int, [c_ctx, P, P, P, C.c_int, P, P]),
     "reloc_db_select": (C.c_int, [c_ctx, C.c_int]),
+    "reloc_db_share": (C.c_int, [c_ctx, c_ctx]),
+    "reloc_d2d": (C.c_int, [c_ctx, P, P, i64]),
+    "reloc_host_alloc": (P, [i64]),
+    "reloc_host_free": (C.c_int, [P]),
+    "reloc_get_stream": (P, [c_ctx]),
+    "reloc_tick_result_dev": (P, [c_ctx]),
     "reloc_db_fetch": (C.c_int, [c_ctx, i64, P, P, P, P, P, P]),
     "reloc_tick_result_ex": (C.c_int, [c_ctx, P, P, P, P, P, P, P, P]),
     "reloc_tick_accumulate_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, P, C.c_int]),

@@ -78,8 +78,8 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->tick_res, 1);
     rc |= dalloc(&c->accum_res, 1);
     rc |= dalloc(&c->tick_flags, 4);
-    rc |= dalloc(&c->scan_ticket, 2);
-    if (rc == 0 && hipMemset(c->scan_ticket, 0, 8) != hipSuccess) rc = RELOC_E_HIP;
+    rc |= dalloc(&c->scan_ticket, 9 * 32);
+    if (rc == 0 && hipMemset(c->scan_ticket, 0, 9 * 32 * 4) != hipSuccess) rc = RELOC_E_HIP;
     return rc;
 }
 
@@ -145,6 +145,10 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->db_shared) {       // the arrays belong to another ctx; only the scratch is ours
+        c->db_desc = nullptr; c->db_pts3d = nullptr; c->db_kp2d = nullptr; c->db_off = nullptr; c->db_pose = nullptr;
+        c->db_xy_heading = nullptr;
+    }
     void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
                     c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
                     c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off,
@@ -235,6 +239,31 @@ RELOC_API int reloc_h2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     return RELOC_OK;
 }
+
+RELOC_API int reloc_d2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    ARG_CHECK_CTX(c, dst && src && bytes >= 0, "reloc_d2d");
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+    return RELOC_OK;
+}
+
+RELOC_API void *reloc_host_alloc(int64_t bytes)
+{
+    void *p = nullptr;
+    if (bytes < 0 || hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault) != hipSuccess) {
+        reloc_set_error("hipHostMalloc(%lld) failed", (long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+RELOC_API int reloc_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return RELOC_OK;
+}
+
+RELOC_API void *reloc_get_stream(reloc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 RELOC_API int reloc_d2h(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
 {

@@ -240,11 +240,12 @@ struct reloc_ctx {
     reloc_params prm;
     int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
-    uint32_t *scan_ticket = nullptr; // 2 words: next record, workgroups that have left (k_db_scan ticket scheduling)
+    uint32_t *scan_ticket = nullptr; // 8 per-XCD record counters + 1 exit counter, 128 bytes apart (k_db_scan ticket scheduling)
 
     // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----
     DbArena db_slot[2];
     int db_sel = 0;
+    bool db_shared = false;          // the selected database's arrays belong to another ctx (reloc_db_share)
     int64_t db_records = 0, db_rows = 0;
     int64_t db_cap_records = 0, db_cap_rows = 0;
     int db_max_rows = 0;

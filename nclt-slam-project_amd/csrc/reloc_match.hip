@@ -37,7 +37,7 @@ typedef uint32_t u32;
 // RELOC_SCAN_PACKED (developer switch, nclt-slam-project_amd/build.py build_variant): 1 = two columns share one 32-bit
 // accumulator and the argmin bookkeeping runs on packed 16-bit halves (see scan_chunk); 0 = one 16-bit key per register.
 #ifndef RELOC_SCAN_PACKED
-#define RELOC_SCAN_PACKED 1
+#define RELOC_SCAN_PACKED 0
 #endif
 __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc)
 {
@@ -334,13 +334,33 @@ __device__ __forceinline__ void db_scan_body(
     if (mask.skip_if && *mask.skip_if != 0) return;       // launch-uniform
 
     // Work distribution.  ticket == NULL: record it = blockIdx.x, + gridDim.x, ... (static).  Otherwise the grid is one
-    // resident generation and every workgroup draws its next record from a counter (ticket[0]); the draw for record
-    // k + 1 is in flight while record k is processed, so its latency is hidden.  The last workgroup to leave
-    // (ticket[1] counts them) puts both words back to zero for the next launch.
-    auto draw = [&]() -> u32 { return atomicAdd(&ticket[0], 1u); };
+    // resident generation and every workgroup draws records from counters, so that all CUs stay full until the last
+    // record (with a static deal the workgroups of a CU finish one after the other and the CU's tail runs at 3, 2, 1
+    // waves per SIMD).  One counter serves ~88 draws per microsecond (measured: 10 000 draws on one word = 143 us), so
+    // there are 8, one per XCD (HW_REG_XCC_ID) on its own 128-byte line: counter x deals records x, x + 8, x + 16, ...;
+    // a workgroup whose counter has run dry moves on to the next one.  The draw for the next record is in flight
+    // while the current one is processed.  The last workgroup to leave (ticket[TICKET_DONE]) zeroes all words.
+    constexpr int TICKET_STRIDE = 32, TICKET_DONE = 8 * TICKET_STRIDE;
+    int shard = 0, dry = 0;
+    if (ticket) {
+        u32 x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+        shard = (int)(x & 7u);
+    }
+    auto draw = [&]() -> u32 { return atomicAdd(&ticket[shard * TICKET_STRIDE], 1u); };
+    // thread 0: turn a drawn ticket into a record index, moving to the next counter while the current one is dry
+    auto settle = [&](u32 t) -> int {
+        for (;;) {
+            const long long rec_i = (long long)shard + 8ll * (long long)t;
+            if (rec_i < n_ids) return (int)rec_i;
+            if (++dry >= 8) return n_ids;
+            shard = (shard + 1) & 7;
+            t = draw();
+        }
+    };
     int it = blockIdx.x;
     if (ticket) {
-        if (tid == 0) wsum[8] = draw();
+        if (tid == 0) wsum[8] = (u32)settle(draw());
         __syncthreads();
         it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
     }
@@ -350,7 +370,7 @@ __device__ __forceinline__ void db_scan_body(
         auto advance = [&]() {
             if (ticket) {
                 __syncthreads();
-                if (tid == 0) wsum[8] = next_ticket;
+                if (tid == 0) wsum[8] = (u32)settle(next_ticket);
                 __syncthreads();
                 it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
             } else {
@@ -433,9 +453,8 @@ __device__ __forceinline__ void db_scan_body(
         advance();
     }
     if (ticket && tid == 0) {
-        if (atomicAdd(&ticket[1], 1u) == gridDim.x - 1) {      // every other workgroup has made its last draw
-            __hip_atomic_store(&ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicAdd(&ticket[TICKET_DONE], 1u) == gridDim.x - 1) {      // every other workgroup has made its last draw
+            for (int x = 0; x <= 8; ++x) __hip_atomic_store(&ticket[x * TICKET_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -582,7 +601,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int resident = ctx->num_cu * 4;          // 4 workgroups of 4 waves per CU (128-VGPR kernel)
     int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
     u32 *ticket = nullptr;
-    if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0) {
+    // (measured r2, L = 10 000 x 64: Q = 500 168.5 vs 171.0 us, L = 100 000 1499 vs 1547 us; the short records of the
+    // 128-column kernel do not cover the draw latency, Q <= 32: 66 vs 55 us, so those keep the static deal)
+    if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0 && nj == 8) {
         ticket = ctx->scan_ticket;
         grid = resident;
     }
@@ -949,8 +970,22 @@ struct DbBuffers {
 }   // namespace
 
 // Grow the selected arena to at least (cap_records, cap_rows); contents are kept.  All-or-nothing.
+// a shared database is dropped (not freed) before this ctx gets one of its own again
+static void db_unshare(reloc_ctx *ctx)
+{
+    if (!ctx->db_shared) return;
+    if (ctx->db_counts) (void)hipFree(ctx->db_counts);
+    if (ctx->topk_part) (void)hipFree(ctx->topk_part);
+    ctx->db_desc = nullptr; ctx->db_pts3d = nullptr; ctx->db_kp2d = nullptr; ctx->db_off = nullptr; ctx->db_pose = nullptr;
+    ctx->db_xy_heading = nullptr; ctx->db_counts = nullptr; ctx->topk_part = nullptr;
+    ctx->db_records = ctx->db_rows = ctx->db_cap_records = ctx->db_cap_rows = 0;
+    ctx->db_max_rows = 0; ctx->topk_blocks = 0;
+    ctx->db_shared = false;
+}
+
 int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
 {
+    if (ctx->db_shared) { reloc_set_error("the selected database is shared from another context (read-only here)"); return RELOC_E_STATE; }
     if (cap_records < 1) cap_records = 1;
     if (cap_rows < 1) cap_rows = 1;
     if (cap_records <= ctx->db_cap_records && cap_rows <= ctx->db_cap_rows && ctx->db_desc) return RELOC_OK;
@@ -986,6 +1021,7 @@ int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         nb.release();
+        (void)hipGetLastError();          // a failed hipMalloc leaves a sticky error that the next launch check would report
         reloc_set_error("database reserve (%lld records, %lld rows) failed: %s", (long long)cap_records, (long long)cap_rows,
                         hipGetErrorString(e));
         return RELOC_E_HIP;
@@ -1028,6 +1064,7 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     ARG_CHECK(n_records == 0 || poses, "poses missing");
     if (n_records > MAX_DB_RECORDS) { reloc_set_error("database: %lld records (max %lld)", (long long)n_records, (long long)MAX_DB_RECORDS); return RELOC_E_CAPACITY; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    db_unshare(ctx);
     // from here on the ctx holds no database until everything below has succeeded
     ctx->db_records = 0;
     ctx->db_rows = 0;
@@ -1071,6 +1108,7 @@ RELOC_API int reloc_db_append(reloc_ctx *ctx, const uint8_t *desc, const float *
                               const double pose[7], const double index_xy[2])
 {
     ARG_CHECK_CTX(ctx, n >= 0 && pose && (n == 0 || (desc && pts3d)), "reloc_db_append");
+    if (ctx->db_shared) { reloc_set_error("the selected database is shared from another context (read-only here)"); return RELOC_E_STATE; }
     if (n > MAX_REC_ROWS) { reloc_set_error("record has %d rows (max %d)", n, MAX_REC_ROWS); return RELOC_E_CAPACITY; }
     int rc = db_make_room(ctx, n);
     if (rc) return rc;
@@ -1104,9 +1142,40 @@ static void db_store_slot(reloc_ctx *ctx)
     a.topk_blocks = ctx->topk_blocks;
 }
 
+RELOC_API int reloc_db_share(reloc_ctx *dst, reloc_ctx *src)
+{
+    ARG_CHECK_CTX(dst, src && src != dst, "reloc_db_share");
+    if (src->device != dst->device) { reloc_set_error("reloc_db_share: contexts live on different devices"); return RELOC_E_ARG; }
+    if (!db_ready(src)) { reloc_set_error("reloc_db_share: the source context has no database"); return RELOC_E_STATE; }
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    int32_t *counts = nullptr;
+    unsigned long long *topk = nullptr;
+    const int blocks = (int)((src->db_cap_records + 1023) / 1024);
+    if (hipMalloc((void **)&counts, (size_t)src->db_cap_records * 4) != hipSuccess ||
+        hipMalloc((void **)&topk, (size_t)blocks * 32 * sizeof(unsigned long long)) != hipSuccess) {
+        if (counts) (void)hipFree(counts);
+        reloc_set_error("reloc_db_share: scratch allocation failed");
+        return RELOC_E_HIP;
+    }
+    if (dst->db_shared) db_unshare(dst);
+    else {
+        void *own[] = {dst->db_desc, dst->db_pts3d, dst->db_kp2d, dst->db_off, dst->db_pose, dst->db_xy_heading, dst->db_counts, dst->topk_part};
+        for (void *q : own) if (q) (void)hipFree(q);
+    }
+    dst->db_desc = src->db_desc; dst->db_pts3d = src->db_pts3d; dst->db_kp2d = src->db_kp2d; dst->db_off = src->db_off;
+    dst->db_pose = src->db_pose; dst->db_xy_heading = src->db_xy_heading;
+    dst->db_counts = counts; dst->topk_part = topk; dst->topk_blocks = blocks;
+    dst->db_records = src->db_records; dst->db_rows = src->db_rows; dst->db_max_rows = src->db_max_rows;
+    dst->db_cap_records = src->db_cap_records; dst->db_cap_rows = src->db_cap_rows;
+    dst->db_shared = true;
+    return RELOC_OK;
+}
+
 RELOC_API int reloc_db_select(reloc_ctx *ctx, int slot)
 {
     ARG_CHECK_CTX(ctx, slot == 0 || slot == 1, "reloc_db_select: slot must be 0 or 1");
+    if (ctx->db_shared) { reloc_set_error("reloc_db_select: the selected database is shared; upload or share per slot instead"); return RELOC_E_STATE; }
     if (slot == ctx->db_sel) return RELOC_OK;
     db_store_slot(ctx);
     const DbArena &a = ctx->db_slot[slot];

@@ -301,6 +301,7 @@ RELOC_API int reloc_tick_accumulate_dev(reloc_ctx *ctx, const uint16_t *depth_mm
 {
     ARG_CHECK_CTX(ctx, depth_mm_dev && base_pose && w >= 64 && h >= 64, "reloc_tick_accumulate_dev");
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+    if (ctx->db_shared) { reloc_set_error("the selected database is shared from another context (read-only here)"); return RELOC_E_STATE; }
     if (ctx->db_records + 1 > ctx->db_cap_records || ctx->db_rows + ctx->max_feat > ctx->db_cap_rows) {
         // grow first (drains the stream): the kernel writes behind the last row without asking
         int rc = db_reserve(ctx, ctx->db_cap_records + ctx->db_cap_records / 2 + 64,

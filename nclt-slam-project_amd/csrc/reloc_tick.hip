@@ -457,6 +457,8 @@ RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *
     return RELOC_OK;
 }
 
+RELOC_API const void *reloc_tick_result_dev(reloc_ctx *ctx) { return ctx ? ctx->tick_res : nullptr; }
+
 RELOC_API int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
                                    int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating)
 {

@@ -32,6 +32,9 @@ class Engine:
         if getattr(self, "_ctx", None):
             self._lib.reloc_destroy(self._ctx)
             self._ctx = None
+            for p in getattr(self, "_pinned", []):
+                self._lib.reloc_host_free(C.c_void_p(p))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -67,6 +70,35 @@ class Engine:
         """enqueue only; `src` must stay alive and unchanged until the stream has passed the copy"""
         assert src.flags["C_CONTIGUOUS"]
         N.check(self._lib.reloc_h2d(self._ctx, C.c_void_p(dst_dev), N.ptr(src), src.nbytes), "reloc_h2d")
+
+    def d2d(self, dst_dev: int, src_dev: int, nbytes: int):
+        N.check(self._lib.reloc_d2d(self._ctx, C.c_void_p(dst_dev), C.c_void_p(src_dev), int(nbytes)), "reloc_d2d")
+
+    def d2h_async(self, dst: np.ndarray, src_dev: int):
+        """enqueue only; read `dst` after sync()"""
+        assert dst.flags["C_CONTIGUOUS"]
+        N.check(self._lib.reloc_d2h(self._ctx, N.ptr(dst), C.c_void_p(src_dev), dst.nbytes), "reloc_d2h")
+
+    def pinned(self, shape, dtype=np.uint8) -> np.ndarray:
+        """numpy array over page-locked host memory (hipHostMalloc): H2D / D2H copies from it are asynchronous DMA"""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self._lib.reloc_host_alloc(n)
+        if not p:
+            raise N.RelocError("reloc_host_alloc failed: " + N.last_error())
+        buf = (C.c_uint8 * max(n, 1)).from_address(p)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return arr
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self._lib.reloc_get_stream(self._ctx) or 0)
+
+    @property
+    def tick_result_dev(self) -> int:
+        return int(self._lib.reloc_tick_result_dev(self._ctx))
 
     def d2h(self, dst: np.ndarray, src_dev: int):
         assert dst.flags["C_CONTIGUOUS"]
@@ -195,6 +227,11 @@ class Engine:
         ixy = None if index_xy is None else np.ascontiguousarray(index_xy, np.float64).reshape(2)
         N.check(self._lib.reloc_db_append(self._ctx, N.ptr(desc), N.ptr(pts3d), N.ptr(kp), len(desc), N.ptr(pose), N.ptr(ixy)),
                 "reloc_db_append")
+
+    def db_share(self, src: "Engine"):
+        """scan the database resident in `src` (same device) instead of holding a copy; read-only through this engine"""
+        N.check(self._lib.reloc_db_share(self._ctx, src._ctx), "reloc_db_share")
+        self._db_owner = src        # keeps the owner alive
 
     def db_select(self, slot: int):
         """switch between the two resident databases (outbound / return leg, X:274-294)"""
@@ -355,10 +392,12 @@ class Engine:
                 "reloc_tick_scan_dev")
 
     def tick_scan_fetch(self, k: int = 25):
-        """(local record ids (k,), counts (k,)) of the last enqueued scan, -1 / 0 padded (synchronises the stream)."""
-        buf = np.empty(64, np.int32)
-        self.d2h(buf, self._topk_dev)
-        return buf[:k].copy(), buf[32:32 + k].copy()
+        """(local record ids (k,), counts (k,), n_features) of the last enqueued scan, -1 / 0 padded (synchronises the stream)."""
+        buf = np.empty(64, np.int32); nf = np.empty(1, np.int32)
+        N.check(self._lib.reloc_d2h(self._ctx, N.ptr(buf), C.c_void_p(self._topk_dev), buf.nbytes), "reloc_d2h")
+        N.check(self._lib.reloc_d2h(self._ctx, N.ptr(nf), C.c_void_p(self._lib.reloc_frame_count_dev(self._ctx)), 4), "reloc_d2h")
+        self.sync()
+        return buf[:k].copy(), buf[32:32 + k].copy(), int(nf[0])
 
     def tick_scan(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
         self.tick_scan_enqueue(img_dev, w, h, base_pose, k, order_rgb)

@@ -64,7 +64,8 @@ def _node_base():
     return Node
 
 
-def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global_reloc=False, fused=False):
+def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global_reloc=False, fused=False, cv2=None):
+    """cv2: the cv2-shaped module the ROS-free core calls (default: the HIP shim); only the non-fused core uses it"""
     from geometry_msgs.msg import PoseWithCovarianceStamped
     from sensor_msgs.msg import Image
     Node = _node_base()
@@ -77,7 +78,7 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
                 self.core = FusedLandmarkMatcher(pkl_path, log_csv, config=cfg, return_landmarks=return_pkl,
                                                  swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
             else:
-                self.core = LandmarkMatcherCore(pkl_path, log_csv, config=cfg, return_landmarks=return_pkl,
+                self.core = LandmarkMatcherCore(pkl_path, log_csv, cv2=cv2, config=cfg, return_landmarks=return_pkl,
                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
             self.last_rgb = self.last_depth = None
             self.create_subscription(Image, "/camera/color/image_raw", self._rgb_cb, 10)
@@ -126,14 +127,14 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
     return VisualLandmarkMatcher()
 
 
-def make_recorder_node(out_pkl, min_disp_m=2.0):
+def make_recorder_node(out_pkl, min_disp_m=2.0, cv2=None):
     from sensor_msgs.msg import Image
     Node = _node_base()
 
     class VisualLandmarkRecorder(Node):
         def __init__(self):
             super().__init__("visual_landmark_recorder")
-            self.core = LandmarkRecorderCore(out_pkl, min_disp_m)
+            self.core = LandmarkRecorderCore(out_pkl, min_disp_m, cv2=cv2)
             self.last_rgb = self.last_depth = None
             self.last_rgb_ts = 0.0
             self.create_subscription(Image, "/camera/color/image_raw", self._rgb_cb, 10)
@@ -182,8 +183,7 @@ def matcher_main(argv=None):
     except KeyboardInterrupt:
         pass
     finally:
-        if not args.fused:
-            node.core.save_augmented()
+        node.core.save_augmented()
         node.destroy_node()
         try:
             rclpy.shutdown()

@@ -19,6 +19,7 @@ import numpy as np
 from .landmarks import shard_by_rows
 
 K_GLOBAL = 25
+MIN_FEATURES = 10      # MIN_MATCHES: fewer current keypoints -> curr_no_features (M:307)
 
 
 def merge_topk(all_ids, all_counts, k=K_GLOBAL):
@@ -47,6 +48,8 @@ class ShardedRelocalizer:
     def _all_gather(self, arr: np.ndarray) -> np.ndarray:
         if self.world == 1:
             return arr[None]
+        if hasattr(self.group, "all_gather_np"):        # in-process group (tests: several shards on one GPU)
+            return self.group.all_gather_np(self.rank, arr)
         import torch
         import torch.distributed as dist
         t = torch.from_numpy(np.ascontiguousarray(arr))
@@ -69,14 +72,22 @@ class ShardedRelocalizer:
             scans = be.scan_batch(frames, base_poses, k)
         else:
             scans = [be.scan(frames[i], base_poses[i], k, i) for i in range(B)]
-        packed = np.zeros((B, 2, k), np.int64)
-        for i, (lids, cnts) in enumerate(scans):
-            packed[i, 0] = np.where(lids >= 0, lids + self.base, -1)
-            packed[i, 1] = cnts
-        allp = self._all_gather(packed)                                       # (world, B, 2, k)
+        # per frame: k global ids, k counts, and the frame's feature count (-1 from a rank that did not extract: an empty
+        # shard) -- the reference decides `curr_no_features` before any candidate work (M:307-309)
+        packed = np.zeros((B, 2 * k + 1), np.int64)
+        for i, scan in enumerate(scans):
+            lids, cnts = scan[0], scan[1]
+            packed[i, :k] = np.where(lids >= 0, lids + self.base, -1)
+            packed[i, k:2 * k] = cnts
+            packed[i, 2 * k] = scan[2] if len(scan) > 2 else MIN_FEATURES
+        allp = self._all_gather(packed)                                       # (world, B, 2k + 1)
+        n_feat = allp[:, :, 2 * k].max(axis=0)
         winners, jobs = [], []
         for i in range(B):
-            win_ids, _ = merge_topk(allp[:, i, 0], allp[:, i, 1], k)
+            if n_feat[i] < MIN_FEATURES:
+                winners.append((np.zeros(0, np.int64), []))
+                continue
+            win_ids, _ = merge_topk(allp[:, i, :k], allp[:, i, k:2 * k], k)
             mine = [(pos, int(g - self.base)) for pos, g in enumerate(win_ids) if self._owns(int(g))]
             winners.append((win_ids, mine))
             if mine:
@@ -88,7 +99,7 @@ class ShardedRelocalizer:
         res = np.zeros((B, 12), np.float64)                                   # [pos, n_inl, reproj, outcome, gid, pose7]
         for i in range(B):
             res[i, 0] = 1e9
-            res[i, 3] = 3 if len(winners[i][0]) else 2
+            res[i, 3] = 1 if n_feat[i] < MIN_FEATURES else (3 if len(winners[i][0]) else 2)
         for (i, _), r in zip(jobs, solved):
             mine = winners[i][1]
             if r["outcome"] in (0, 4):
@@ -130,11 +141,19 @@ class HipShard:
         a, b = int(bounds[rank]), int(bounds[rank + 1])
         off = np.asarray(offsets[a:b + 1], np.int64) - int(offsets[a])
         self.engines = [engine] + [Engine(engine.device, engine.max_w, engine.max_h, engine.max_feat) for _ in range(n_slots - 1)]
-        for e in self.engines:
-            e.db_upload(desc[offsets[a]:offsets[b]], pts3d[offsets[a]:offsets[b]], off, poses[a:b])
+        if b > a:
+            # one resident copy of the shard; the other slots (streams) scan it through reloc_db_share
+            engine.db_upload(desc[offsets[a]:offsets[b]], pts3d[offsets[a]:offsets[b]], off, poses[a:b])
+            for e in self.engines[1:]:
+                e.db_share(engine)
         self.engine, self.base, self.n_records, self.w, self.h = engine, a, b - a, w, h
 
+    def _empty(self, k):
+        return np.full(k, -1, np.int32), np.zeros(k, np.int32), -1
+
     def scan(self, frame_dev, base_pose, k, slot=0):
+        if self.n_records == 0:                      # more ranks than records: this rank only takes part in the exchange
+            return self._empty(k)
         return self.engines[slot].tick_scan(frame_dev, self.w, self.h, base_pose, k)
 
     def solve(self, local_ids, base_pose, check_consistency, seed, slot=0):
@@ -143,6 +162,8 @@ class HipShard:
     def scan_batch(self, frames_dev, base_poses, k):
         if len(frames_dev) > len(self.engines):
             raise ValueError(f"batch of {len(frames_dev)} frames on a shard with {len(self.engines)} slots")
+        if self.n_records == 0:
+            return [self._empty(k) for _ in frames_dev]
         for i, f in enumerate(frames_dev):
             self.engines[i].tick_scan_enqueue(f, self.w, self.h, base_poses[i], k)
         return [self.engines[i].tick_scan_fetch(k) for i in range(len(frames_dev))]

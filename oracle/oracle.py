@@ -17,7 +17,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libreloc_oracle.so")
+_FAST_PATH = os.path.join(_HERE, "_build", "libreloc_oracle_fast.so")
 _lib = None
+_libs = {}
 
 NLEVELS = 8
 
@@ -33,22 +35,44 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def build_fast() -> str:
+    """The timing-only -O3 -march=native build (bench.py cpu_baseline); compiled on the machine that runs it."""
+    subprocess.run(["make", "-C", _HERE, "-B", "fast"], check=True, stdout=subprocess.DEVNULL)
+    return _FAST_PATH
+
+
+def select(fast: bool):
+    """Route every call below to the strict build (default, what the tests check against) or the timing-only build."""
+    global _lib
+    key = "fast" if fast else "strict"
+    if key not in _libs:
+        if fast and not os.path.exists(_FAST_PATH):
+            build_fast()
+        _libs[key] = _load(_FAST_PATH if fast else build())
+    _lib = _libs[key]
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.orc_harris_px.restype = C.c_float
-        _lib.orc_ic_angle.restype = C.c_float
-        _lib.orc_fast_atan2_deg.restype = C.c_float
-        _lib.orc_fast_atan2_deg.argtypes = [C.c_float, C.c_float]
-        _lib.orc_log_spec.restype = C.c_double
-        _lib.orc_log_spec.argtypes = [C.c_double]
-        _lib.orc_pnp_refine.restype = C.c_double
-        _lib.orc_ransac_update_iters.argtypes = [C.c_double, C.c_double, C.c_int]
-        _lib.orc_sincos_spec.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        _lib = _libs["strict"] = _load(_LIB_PATH)
     return _lib
+
+
+def _load(path):
+    so = C.CDLL(path)
+    so.orc_harris_px.restype = C.c_float
+    so.orc_ic_angle.restype = C.c_float
+    so.orc_fast_atan2_deg.restype = C.c_float
+    so.orc_fast_atan2_deg.argtypes = [C.c_float, C.c_float]
+    so.orc_log_spec.restype = C.c_double
+    so.orc_log_spec.argtypes = [C.c_double]
+    so.orc_pnp_refine.restype = C.c_double
+    so.orc_ransac_update_iters.argtypes = [C.c_double, C.c_double, C.c_int]
+    so.orc_sincos_spec.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    return so
 
 
 def _p(a):
@@ -220,6 +244,11 @@ def match_knn2(q, t):
 def set_threads(n: int):
     """threads of the whole-database scan (the only multi-threaded oracle routine); default 1"""
     lib().orc_set_threads(int(n))
+
+
+def set_single_pass(on: bool):
+    """db_match_counts: evaluate each distance once (timing variant, bench.py cpu_baseline) instead of the literal two passes"""
+    lib().orc_set_single_pass(int(on))
 
 
 def db_match_counts(db, offsets, cur):

@@ -106,6 +106,34 @@ ORC_API int orc_match_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, i
 static int g_threads = 1;
 ORC_API void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 
+/* Same count with every distance evaluated ONCE (row and column minima tracked together, lowest index on ties both
+ * ways): what a CPU implementation would do; used only for bench.py's cpu_baseline timing and held equal to the
+ * literal two-pass restatement above by tests/test_oracle_known_answers.py. */
+static int g_single_pass = 0;
+ORC_API void orc_set_single_pass(int on) { g_single_pass = on != 0; }
+
+static int mutual_count_single_pass(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *colkey /* nt */)
+{
+    if (nq <= 0 || nt <= 0) return 0;
+    /* key = distance << 16 | index of the other side: min(key) = smallest distance, lowest index on ties */
+    for (int j = 0; j < nt; ++j) colkey[j] = 0x7fffffff;
+    int n = 0;
+    int32_t *rowkey = malloc(sizeof(int32_t) * (size_t)nq);
+    for (int i = 0; i < nq; ++i) {
+        int32_t best = 0x7fffffff;
+        for (int j = 0; j < nt; ++j) {
+            const int d = ham256(q + 32 * (size_t)i, t + 32 * (size_t)j);
+            const int32_t kr = (d << 16) | j, kc = (d << 16) | i;
+            if (kr < best) best = kr;
+            if (kc < colkey[j]) colkey[j] = kc;
+        }
+        rowkey[i] = best;
+    }
+    for (int i = 0; i < nq; ++i) n += (colkey[rowkey[i] & 0xffff] & 0xffff) == i;
+    free(rowkey);
+    return n;
+}
+
 ORC_API int orc_db_match_counts(const uint8_t *db, const int64_t *offsets, int64_t n_rec,
                                 const uint8_t *cur, int n_cur, int32_t *counts)
 {
@@ -118,13 +146,17 @@ ORC_API int orc_db_match_counts(const uint8_t *db, const int64_t *offsets, int64
     {
         int32_t *qi = malloc(sizeof(int32_t) * (size_t)cap), *ti = malloc(sizeof(int32_t) * (size_t)cap);
         int32_t *dd = malloc(sizeof(int32_t) * (size_t)cap);
+        int32_t *ck = malloc(sizeof(int32_t) * (size_t)(n_cur > 0 ? n_cur : 1));
 #pragma omp for schedule(dynamic, 16)
         for (int64_t r = 0; r < n_rec; ++r) {
             int32_t n = 0;
-            orc_match_mutual(db + 32 * offsets[r], (int)(offsets[r + 1] - offsets[r]), cur, n_cur, qi, ti, dd, &n);
+            if (g_single_pass && n_cur <= 0xffff && offsets[r + 1] - offsets[r] <= 0xffff)
+                n = mutual_count_single_pass(db + 32 * offsets[r], (int)(offsets[r + 1] - offsets[r]), cur, n_cur, ck);
+            else
+                orc_match_mutual(db + 32 * offsets[r], (int)(offsets[r + 1] - offsets[r]), cur, n_cur, qi, ti, dd, &n);
             counts[r] = n;
         }
-        free(qi); free(ti); free(dd);
+        free(qi); free(ti); free(dd); free(ck);
     }
     return 0;
 }

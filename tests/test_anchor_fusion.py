@@ -55,3 +55,32 @@ def test_replay_teach_repeat_fusion(oracle):
         regimes.append(f.blend(100.0 + 0.5 * i + 0.05, (x, y), (x + 0.1, y)).regime)
     assert regimes[0] == "ok" and regimes[-1] == "strong"
     assert math.isfinite(f.anchor_last[1])
+
+
+def test_fusion_reproduces_the_reference_relay():
+    """tests/golden/anchor_fusion.json: the reference's unmodified relay (`_anchor_cb` T:235-256, regime switch and blend
+    T:533-591) driven tick by tick (tests/golden/make_anchor_fusion_golden.py).  AnchorFusion must land in the same
+    regime, with the same hysteresis streak, the same no-anchor SLAM weight and the same blended nav position."""
+    import json, os
+    from nclt_slam_project_amd import anchor_fusion as AF
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "anchor_fusion.json")))
+    th = g["thresholds"]
+    assert (AF.ANCHOR_STALE_S, AF.ANCHOR_STRONG_STD, AF.ANCHOR_OK_STD, AF.ANCHOR_HYSTERESIS_N) == \
+           (th["stale"], th["strong"], th["ok"], th["hysteresis"])
+    f = AnchorFusion()
+    seen, alphas = set(), set()
+    for r in g["rows"]:
+        now = 1000.0 + r["t"]
+        if r["anchor"] is not None:
+            f.on_anchor(now, r["anchor"][0], r["anchor"][1], r["anchor"][2])
+        if r["nav"] is None:
+            continue                       # the relay's first tick only initialises its encoder odometry
+        out = f.blend(now, r["slam"], r["enc"])
+        assert out.regime == r["regime"] and f.anchor_strong_streak == r["streak"], r
+        assert out.x == pytest.approx(r["nav"][0], abs=1e-12) and out.y == pytest.approx(r["nav"][1], abs=1e-12), r
+        assert out.anchor_staleness == pytest.approx(r["staleness"], abs=1e-9) and out.anchor_std == pytest.approx(r["std"], abs=1e-15)
+        if r["regime"] == "no_anchor":
+            assert out.alpha == r["alpha"], r
+            alphas.add(out.alpha)
+        seen.add(out.regime)
+    assert seen == {"no_anchor", "ok", "strong"} and alphas == {0.95, 0.70, 0.40, 0.10}

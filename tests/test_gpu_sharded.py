@@ -67,7 +67,8 @@ def test_topk_when_one_thread_owns_most_winners(engine, oracle):
     poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1))
     engine.db_upload(desc, pts, off, poses)
     frame_dev = engine.to_device(img)
-    ids, cnt = engine.tick_scan(frame_dev, 640, 480, None, k=25)
+    ids, cnt, n_feat = engine.tick_scan(frame_dev, 640, 480, None, k=25)
+    assert n_feat == feat["n"]
     engine.dev_free(frame_dev)
     counts = oracle.db_match_counts(desc, off, feat["desc"])
     exp = oracle.topk_records(counts, 10, 25)

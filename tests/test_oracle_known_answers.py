@@ -255,6 +255,27 @@ def test_db_counts_and_topk(oracle):
 
 
 # ---------------------------------------------------------------- PnP
+def test_single_pass_scan_equals_the_literal_two_pass_matcher(oracle):
+    """bench.py's cpu_baseline times the scan with every distance evaluated once; it must count exactly what the literal
+    restatement (forward nearest + reverse nearest, orc_match_mutual) counts, massive distance ties included"""
+    rng = np.random.default_rng(17)
+    cur = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    from nclt_slam_project_amd import synth
+    desc, pts, off, poses = synth.descriptor_db(rng, 120, "ragged", cur, planted_records=(2, 60, 119))
+    desc[off[5]:off[6], 1:] = 0            # low-entropy rows: many equal distances
+    desc[off[9]:off[10]] = desc[off[9]]    # identical rows: ties broken by the lowest index
+    cur2 = cur.copy(); cur2[40:60] = cur2[40]
+    for c in (cur, cur2, cur[:1], cur[:0]):
+        oracle.set_single_pass(False)
+        a = oracle.db_match_counts(desc, off, c)
+        oracle.set_single_pass(True)
+        try:
+            b = oracle.db_match_counts(desc, off, c)
+        finally:
+            oracle.set_single_pass(False)
+        np.testing.assert_array_equal(a, b)
+
+
 def test_sampler_distinct_and_deterministic(oracle):
     for m in (4, 5, 17, 500):
         for h in range(50):

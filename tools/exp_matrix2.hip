@@ -1,0 +1,144 @@
+// Developer experiment (round 2): the production u16 distance-matrix kernel (persistent grid, A rows prefetched through
+// the scalar cache, 8 B rows per lane, one 16-byte store per lane and A row) with its two halves separated and a few
+// variants, to see what the VALU part and the store stream cost on their own and how well they overlap.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/exp_matrix2 tools/exp_matrix2.hip && ./tools/exp_matrix2
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+typedef uint32_t u32;
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) { u32 r; asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc)); return r; }
+__device__ __forceinline__ void srow_landed(u32 first_dword) { asm volatile("" ::"s"(first_dword)); }
+__device__ __forceinline__ u32 ham8(const u32 q[8], const uint4 a, const uint4 b, u32 init)
+{
+    u32 acc = init;
+    acc = bcnt_acc(q[0] ^ a.x, acc); acc = bcnt_acc(q[1] ^ a.y, acc); acc = bcnt_acc(q[2] ^ a.z, acc); acc = bcnt_acc(q[3] ^ a.w, acc);
+    acc = bcnt_acc(q[4] ^ b.x, acc); acc = bcnt_acc(q[5] ^ b.y, acc); acc = bcnt_acc(q[6] ^ b.z, acc); acc = bcnt_acc(q[7] ^ b.w, acc);
+    return acc;
+}
+// MODE 0 full, 1 compute only (store behind a never-true test), 2 store only (no distances)
+// ST    0 plain store, 1 nontemporal, 2 sc1 (write-through) via inline asm
+// IL    1 serial chains, 2 two packed registers interleaved
+template <int MODE, int ST, int IL, int UNIT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k(const uint4 *__restrict__ A, int64_t na, const uint4 *__restrict__ B, int64_t nb,
+                                              uint16_t *__restrict__ out, int n_col_tiles, int n_units)
+{
+    const int ct = blockIdx.x % n_col_tiles;
+    const int k0 = blockIdx.x / n_col_tiles, kstep = gridDim.x / n_col_tiles;
+    const int64_t j0 = ((int64_t)ct * 256 + threadIdx.x) * 8;
+    u32 b[8][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int64_t j = j0 + c < nb ? j0 + c : nb - 1;
+        const uint4 lo = B[2 * j], hi = B[2 * j + 1];
+        b[c][0] = lo.x; b[c][1] = lo.y; b[c][2] = lo.z; b[c][3] = lo.w; b[c][4] = hi.x; b[c][5] = hi.y; b[c][6] = hi.z; b[c][7] = hi.w;
+    }
+    if (j0 >= nb) return;
+    const int64_t last = na - 1;
+    auto row_at = [&](int64_t i) { return i < last ? i : last; };
+    int64_t i_first = row_at((int64_t)k0 * UNIT);
+    uint4 ra = A[2 * i_first], rb = A[2 * i_first + 1];
+    for (int unit = k0; unit < n_units; unit += kstep) {
+        const int64_t i0 = (int64_t)unit * UNIT;
+#pragma unroll
+        for (int e = 0; e < UNIT; ++e) {
+            srow_landed(ra.x);
+            const int64_t inext = row_at(e + 1 < UNIT ? i0 + e + 1 : i0 + (int64_t)kstep * UNIT);
+            const uint4 na_ = A[2 * inext], nb_ = A[2 * inext + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            u32 w[4];
+            if (MODE == 2) {
+                w[0] = ra.x ^ b[0][0]; w[1] = ra.y ^ b[1][0]; w[2] = ra.z ^ b[2][0]; w[3] = ra.w ^ b[3][0];
+            } else if (IL == 1) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const u32 odd = ham8(b[2 * p + 1], ra, rb, 0);
+                    w[p] = ham8(b[2 * p], ra, rb, odd << 16);
+                }
+            } else {
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+                for (int p = 0; p < 4; p += 2) {
+                    u32 o0 = 0, o1 = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p + 1][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 3][q] ^ rw[q], o1); }
+                    o0 <<= 16; o1 <<= 16;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 2][q] ^ rw[q], o1); }
+                    w[p] = o0; w[p + 1] = o1;
+                }
+            }
+            const bool doit = MODE == 1 ? (w[0] == 0xdeadbeefu && w[1] == 0x12345678u) : (i0 + e < na);
+            if (doit) {
+                uint16_t *o = out + (i0 + e) * nb + j0;
+                const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+                if (ST == 0) *reinterpret_cast<uint4 *>(o) = v;
+                else if (ST == 1) {
+                    typedef u32 v4u __attribute__((ext_vector_type(4)));
+                    v4u vv = {w[0], w[1], w[2], w[3]};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<v4u *>(o));
+                }
+                else {
+                    typedef u32 v4u __attribute__((ext_vector_type(4)));
+                    v4u vv = {w[0], w[1], w[2], w[3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(vv) : "memory");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ra = na_;
+            rb = nb_;
+        }
+    }
+}
+template <int MODE, int ST, int IL, int UNIT, int WPS> void run(const char *name, const uint4 *A, const uint4 *B, uint16_t *out, int64_t F, int64_t K, int per_cu)
+{
+    const int n_col_tiles = (int)((K + 2047) / 2048);
+    const int n_units = (int)((F + UNIT - 1) / UNIT);
+    int api = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k<MODE, ST, IL, UNIT, WPS>, 256, 0);
+    hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void *)k<MODE, ST, IL, UNIT, WPS>);
+    if (per_cu <= 0) per_cu = api;
+    int grid = 256 * per_cu / n_col_tiles * n_col_tiles; if (grid < n_col_tiles) grid = n_col_tiles;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k<MODE, ST, IL, UNIT, WPS>), dim3(grid), dim3(256), 0, 0, A, F, B, K, out, n_col_tiles, n_units);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<MODE, ST, IL, UNIT, WPS>), dim3(grid), dim3(256), 0, 0, A, F, B, K, out, n_col_tiles, n_units);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= 5;
+        if (ms < best) best = ms;
+    }
+    printf("%-44s regs=%3d api=%d per_cu=%d grid=%5d %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s  %.2f T pairs/s\n", name, fa.numRegs, api, per_cu, grid,
+           best * 1e3, 2.0 * F * K / best / 1e6, 2.0 * F * K / best / 1e6 / 80.0, (double)F * K / best / 1e9);
+    fflush(stdout);
+}
+int main()
+{
+    const int64_t F = 20000, K = 20000;
+    std::vector<uint32_t> h((size_t)F * 8);
+    uint64_t s = 88172645463325252ull;
+    for (size_t i = 0; i < h.size(); ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint32_t)(s >> 16); }
+    uint4 *A, *B; uint16_t *out;
+    (void)hipMalloc(&A, F * 32); (void)hipMalloc(&B, K * 32); (void)hipMalloc(&out, F * K * 2 + 4096);
+    (void)hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
+    run<0, 0, 1, 8, 1>("full  plain serial u8", A, B, out, F, K, 0);
+    run<1, 0, 1, 8, 1>("compute-only serial u8", A, B, out, F, K, 0);
+    run<2, 0, 1, 8, 1>("store-only plain u8", A, B, out, F, K, 0);
+    run<2, 1, 1, 8, 1>("store-only nt u8", A, B, out, F, K, 0);
+    run<2, 2, 1, 8, 1>("store-only sc1 u8", A, B, out, F, K, 0);
+    run<2, 0, 1, 8, 1>("store-only plain u8 per_cu=4", A, B, out, F, K, 4);
+    run<2, 1, 1, 8, 1>("store-only nt u8 per_cu=4", A, B, out, F, K, 4);
+    run<0, 1, 1, 8, 1>("full  nt serial u8", A, B, out, F, K, 0);
+    run<0, 2, 1, 8, 1>("full  sc1 serial u8", A, B, out, F, K, 0);
+    run<0, 0, 2, 8, 1>("full  plain interleave2 u8", A, B, out, F, K, 0);
+    run<1, 0, 2, 8, 1>("compute-only interleave2 u8", A, B, out, F, K, 0);
+    run<0, 1, 2, 8, 1>("full  nt interleave2 u8", A, B, out, F, K, 0);
+    run<0, 0, 1, 16, 1>("full  plain serial u16", A, B, out, F, K, 0);
+    run<0, 0, 1, 8, 1>("full  plain serial u8 per_cu=5", A, B, out, F, K, 5);
+    run<0, 0, 1, 8, 1>("full  plain serial u8 per_cu=4", A, B, out, F, K, 4);
+    run<0, 1, 1, 8, 1>("full  nt serial u8 per_cu=5", A, B, out, F, K, 5);
+    run<0, 1, 1, 8, 1>("full  nt serial u8 per_cu=4", A, B, out, F, K, 4);
+    run<1, 0, 1, 8, 1>("compute-only serial u8 per_cu=4", A, B, out, F, K, 4);
+    return 0;
+}
