@@ -449,6 +449,10 @@ __device__ __forceinline__ void db_scan_body(
         if (tid == 0) {
             if (counts) counts[EMIT ? it : r] = (int32_t)base;
             if (EMIT && m_n) m_n[it] = (int32_t)base;
+            if (!EMIT && mask.elig && (int)base >= mask.elig_min) {
+                const int p = atomicAdd(mask.elig_n, 1);
+                if (p < mask.elig_cap) mask.elig[p] = ((unsigned long long)base << 32) | (unsigned)(r + 1);
+            }
         }
         advance();
     }
@@ -701,30 +705,48 @@ __device__ __forceinline__ void matrix_body(const uint4 *__restrict__ A, int64_t
     if (!FULL && j0 >= nb) return;
     // A rows come through the scalar cache, one fetch in flight: the fetch of the next row (of this unit,
     // or the first row of this workgroup's next unit) is issued as soon as the current row has landed and
-    // hides behind the current row's ~135 VALU instructions (see srow_landed)
-    const int64_t last = na - 1;
-    auto row_at = [&](int64_t i) { return i < last ? i : last; };
-    int64_t i_first = row_at((int64_t)k0 * MAT_UNIT_ROWS);
-    uint4 ra = A[2 * i_first], rb = A[2 * i_first + 1];
+    // hides behind the current row's ~135 VALU instructions (see srow_landed).
+    // Measured r2 (tools/exp_matrix2.hip, interleaved rounds on one MI355X, 20000 x 20000): the r1 form of this loop
+    // 218 us; non-temporal stores (the 800 MB output is written once and never read here: nt keeps it from evicting the
+    // B rows' lines and its store stream alone runs 6.3 instead of 5.7 TB/s) 202 us; two distance chains interleaved
+    // and 5 resident workgroups per CU 199 us = 0.50 of 8 TB/s, within 4 % of the same loop without its store (190 us):
+    // the kernel is bound by the VALU's 2.1 T pairs/s on this formulation, not by HBM.
+    // row indices are 32-bit (launch_matrix checks na < 2^31): clamps and bound tests stay on the scalar unit
+    const int last = (int)na - 1, n_rows = (int)na;
+    auto row_at = [&](int i) { return min(i, last); };
+    const int i_first = row_at(k0 * MAT_UNIT_ROWS);
+    uint4 ra = A[2 * (int64_t)i_first], rb = A[2 * (int64_t)i_first + 1];
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const u32 lane_off = (u32)(j0 * 2);                                   // byte offset inside an output row: the row base is wave-uniform
     for (int unit = k0; unit < n_units; unit += kstep) {
-        const int64_t i0 = (int64_t)unit * MAT_UNIT_ROWS;
+        const int i0 = unit * MAT_UNIT_ROWS;
+        const bool whole = i0 + MAT_UNIT_ROWS <= n_rows;                  // wave-uniform: no per-row bound checks in whole units
 #pragma unroll
         for (int e = 0; e < MAT_UNIT_ROWS; ++e) {
             srow_landed(ra.x);
-            const int64_t inext = row_at(e + 1 < MAT_UNIT_ROWS ? i0 + e + 1 : i0 + (int64_t)kstep * MAT_UNIT_ROWS);
-            const uint4 na_ = A[2 * inext], nb_ = A[2 * inext + 1];
+            const int inext = row_at(e + 1 < MAT_UNIT_ROWS ? i0 + e + 1 : i0 + kstep * MAT_UNIT_ROWS);
+            const uint4 na_ = A[2 * (int64_t)inext], nb_ = A[2 * (int64_t)inext + 1];
             __builtin_amdgcn_sched_barrier(0);
+            const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
             u32 w[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const u32 odd = ham8(b[2 * p + 1], ra, rb, 0);
-                w[p] = ham8(b[2 * p], ra, rb, odd << 16);
+            for (int p = 0; p < 4; p += 2) {                              // two packed registers = two chains interleaved
+                u32 o0 = 0, o1 = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p + 1][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 3][q] ^ rw[q], o1); }
+                o0 <<= 16; o1 <<= 16;                                     // odd column's distance in the high half seeds the even column's chain
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 2][q] ^ rw[q], o1); }
+                w[p] = o0; w[p + 1] = o1;
             }
-            if (i0 + e < na) {
-                uint16_t *o = out + (i0 + e) * nb + j0;
+            if (whole || i0 + e < n_rows) {
+                char *row = reinterpret_cast<char *>(out + (int64_t)(i0 + e) * nb);            // scalar registers
                 if (FULL || j0 + 8 <= nb) {
-                    *reinterpret_cast<uint4 *>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    // SGPR row base + 32-bit lane offset: no vector address arithmetic per row; non-temporal
+                    const v4u v = {w[0], w[1], w[2], w[3]};
+                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
                 } else {
+                    uint16_t *o = reinterpret_cast<uint16_t *>(row + lane_off);
                     for (int c = 0; c < 8 && j0 + c < nb; ++c) o[c] = (uint16_t)(w[c >> 1] >> ((c & 1) * 16));
                 }
             }
@@ -765,7 +787,7 @@ static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uin
     if (nb % 8 == 0 && ((uintptr_t)out & 15) == 0) {
         const int n_col_tiles = (int)((nb + 2047) / 2048);
         const int64_t n_units = (na + MAT_UNIT_ROWS - 1) / MAT_UNIT_ROWS;
-        if (n_col_tiles > 4096 || n_units > 0x7fffffff) { reloc_set_error("hamming matrix: shape too large"); return RELOC_E_CAPACITY; }
+        if (n_col_tiles > 4096 || na > 0x7ffffff0 || nb * 2 > 0xffffffffll) { reloc_set_error("hamming matrix: shape too large"); return RELOC_E_CAPACITY; }
         static int per_cu = 0;
         if (!per_cu) {
             // blocks of 4 waves = one wave per SIMD each: residency = waves per SIMD the register
@@ -779,7 +801,7 @@ static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uin
             }
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k_hamming_matrix, 256, 0) == hipSuccess && api > 0 && api < per_cu)
                 per_cu = api;
-            if (per_cu > 6) per_cu = 6;
+            if (per_cu > 5) per_cu = 5;           // measured: 4 / 5 / 6 resident workgroups per CU 204 / 199 / 200 us
             if (per_cu < 1) per_cu = 1;
         }
         int grid = ctx->num_cu * per_cu;

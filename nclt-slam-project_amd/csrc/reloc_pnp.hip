@@ -380,6 +380,52 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// 28 wave-wide sums with the summation tree of wave_sum (v[l] + v[l ^ 32], then ^ 16, ^ 8, ^ 4, ^ 2, ^ 1: identical
+// rounding, IEEE addition is commutative) but as ONE transposing butterfly over all values: at every step half of the
+// lanes keep one half of the registers and the other lanes the other half, so step s costs 32 / 2^s additions instead
+// of 28.  Step ^32 / ^16 exchange through v_permlane32_swap / v_permlane16_swap (the swap hands each side exactly
+// the halves it needs), the in-row steps through DPP.  Afterwards lane 2 k (and 2 k + 1) holds the total of value k;
+// v_readlane broadcasts the 28 totals.  v[28..31] must be zero.  (k_pnp_finish is one wave per candidate, so the
+// length of this dependent chain IS the kernel's run time: 43 -> see DESIGN.md.)
+__device__ __forceinline__ void wave_sum28(double (&v)[32], double (&tot)[28])
+{
+    auto lo32 = [](double x) { return (unsigned)__double_as_longlong(x); };
+    auto hi32 = [](double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); };
+    auto mk = [](unsigned l, unsigned h) { return __longlong_as_double((long long)(((unsigned long long)h << 32) | l)); };
+    const int lane = threadIdx.x & 63;
+    double r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {       // ^32: lanes 0-31 keep value k, lanes 32-63 value k + 16
+        const auto a = __builtin_amdgcn_permlane32_swap(lo32(v[k]), lo32(v[k + 16]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi32(v[k]), hi32(v[k + 16]), false, false);
+        r[k] = mk(a[0], b[0]) + mk(a[1], b[1]);
+    }
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {        // ^16: even rows keep r[k], odd rows r[k + 8]
+        const auto a = __builtin_amdgcn_permlane16_swap(lo32(r[k]), lo32(r[k + 8]), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi32(r[k]), hi32(r[k + 8]), false, false);
+        t[k] = mk(a[0], b[0]) + mk(a[1], b[1]);
+    }
+    // in-row steps: lanes with the step's bit clear keep the first register of a pair, the others the second
+    auto step = [&](double a, double b, int bit, auto xchg) {
+        const bool hi = lane & bit;
+        const double mine = hi ? b : a, theirs = hi ? a : b;
+        return mine + mk(xchg(lo32(theirs)), xchg(hi32(theirs)));
+    };
+    double u[4], w[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = step(t[k], t[k + 4], 8, [](unsigned x) { return dpp_xor<8>(x); });
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w[k] = step(u[k], u[k + 2], 4, [](unsigned x) { return dpp_xor<4>(x); });
+    double x = step(w[0], w[1], 2, [](unsigned y) { return dpp_xor<2>(y); });
+    x = x + mk(dpp_xor<1>(lo32(x)), dpp_xor<1>(hi32(x)));
+    const unsigned xl = lo32(x), xh = hi32(x);
+#pragma unroll
+    for (int k = 0; k < 28; ++k)
+        tot[k] = mk((unsigned)__builtin_amdgcn_readlane((int)xl, 2 * k), (unsigned)__builtin_amdgcn_readlane((int)xh, 2 * k));
+}
+
 // Normal equations of the reprojection cost over the selected points, summed across the wave.
 // H: upper triangle (21 values, row-major a<=b), g: 6, returns the cost; every lane gets the sums.
 __device__ double lm_normal_wave(const float *obj, const float *img, const int32_t *sel, int n, const double *Rt,
@@ -414,9 +460,16 @@ __device__ double lm_normal_wave(const float *obj, const float *img, const int32
         }
         cost += ru * ru + rv * rv;
     }
-    for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
-    for (int k = 0; k < 6; ++k) g[k] = wave_sum(g[k]);
-    return wave_sum(cost);
+    // 28 wave-wide sums at once (see wave_sum28): ~130 VALU instructions instead of 28 x 30
+    double v[32], tot[28];
+    for (int k = 0; k < 21; ++k) v[k] = H[k];
+    for (int k = 0; k < 6; ++k) v[21 + k] = g[k];
+    v[27] = cost;
+    v[28] = v[29] = v[30] = v[31] = 0.0;
+    wave_sum28(v, tot);
+    for (int k = 0; k < 21; ++k) H[k] = tot[k];
+    for (int k = 0; k < 6; ++k) g[k] = tot[21 + k];
+    return tot[27];
 }
 
 __device__ bool chol_solve6(const double Ain[36], const double b[6], double x[6])

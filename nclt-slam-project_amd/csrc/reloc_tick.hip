@@ -175,6 +175,11 @@ struct CountKey {
     }
 };
 
+struct ListKey {
+    const unsigned long long *keys;
+    __device__ unsigned long long operator()(int i) const { return keys[i]; }
+};
+
 struct PartKey {
     const unsigned long long *part;
     int k;
@@ -232,12 +237,18 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__res
                                                             const unsigned long long *__restrict__ part, int n_blocks,
                                                             int32_t *__restrict__ out_ids, int32_t *__restrict__ out_counts,
                                                             int32_t *__restrict__ out_n, const int32_t *skip_if,
-                                                            int32_t *__restrict__ relocating)
+                                                            int32_t *__restrict__ relocating,
+                                                            const unsigned long long *__restrict__ elig, int32_t *elig_n, int elig_cap)
 {
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     if (skip_if && *skip_if != 0) return;                       // block-uniform; out_n (may alias skip_if) is written last
-    const int n = topk_final(CountKey{counts, min_matches}, L, k, part, n_blocks, s_red, s_keys);
+    // the scan has left the keys of the records with >= min_matches mutual matches in `elig` (normally a handful): rank
+    // those; only when more than elig_cap records qualified (elig_n counts all offers) walk the counts themselves
+    int n;
+    const int n_elig = elig ? *elig_n : -1;
+    if (n_elig >= 0 && n_elig <= elig_cap) n = block_topk(0, n_elig, k, ListKey{elig}, s_red, s_keys);
+    else n = topk_final(CountKey{counts, min_matches}, L, k, part, n_blocks, s_red, s_keys);
     __syncthreads();
     const int tid = threadIdx.x;
     if (tid < k) {
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__res
     if (tid == 0) {
         *out_n = n;
         if (relocating) *relocating = 1;
+        if (elig) *elig_n = 0;                                   // ready for the next scan on this stream
     }
 }
 
@@ -274,12 +286,12 @@ static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t 
     const int L = (int)ctx->db_records;
     const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
     const int mm = ctx->prm.min_matches;
-    if (nb)
-        hipLaunchKernelGGL(k_topk_part<CountKey>, dim3(nb), dim3(TICK_BLOCK), 0, ctx->stream, CountKey{ctx->db_counts, mm}, L, k,
-                           ctx->topk_part);
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, mm, ctx->topk_part, nb,
+    // the scan of this tick has listed the eligible records (scan_mask_elig): one launch ranks them.  In the rare
+    // overflow case the same kernel walks all L counts with one block (n_blocks = 0): slow, but exact.
+    (void)nb;
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, mm, ctx->topk_part, 0,
                        out_ids, out_counts, ctx->cand_n, auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr,
-                       ctx->tick_flags);
+                       ctx->tick_flags, ctx->elig, ctx->elig_n, ELIG_CAP);
 }
 
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
     if (best < 0) {
         if (s == 0) {
             TickResult out;
+            out.pad[0] = out.pad[1] = 0;
             for (int k = 0; k < 7; ++k) out.anchor_pose[k] = 0;
             out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.relocating = relocating; out.n_features = nfeat; out.n_candidates = nc;
             out.outcome = nfeat < prm.min_matches ? RELOC_OUT_NO_FEATURES : (nc == 0 ? RELOC_OUT_NO_CANDIDATES : RELOC_OUT_NO_PNP_ACCEPT);
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
     }
     if (key == best) {
         TickResult out;
+        out.pad[0] = out.pad[1] = 0;
         for (int k = 0; k < 7; ++k) out.anchor_pose[k] = pose[k];
         out.n_inl = inl; out.reproj = err; out.lm_idx = cand_ids[s]; out.relocating = relocating; out.n_features = nfeat; out.n_candidates = nc;
         const double dx = pose[0] - prm.base_pose[0], dy = pose[1] - prm.base_pose[1];
@@ -430,6 +444,7 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
         for (int k = 0; k < 4; ++k) mask.q[k] = base_pose[3 + k];
         mask.cos_tol = prm.cos_tol;
         mask.skip_if = mode == RELOC_TICK_AUTO ? ctx->cand_n : nullptr;
+        mask.elig = ctx->elig; mask.elig_n = ctx->elig_n; mask.elig_min = ctx->prm.min_matches; mask.elig_cap = ELIG_CAP;
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                             ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
@@ -502,6 +517,7 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     mask.xyh = base_pose ? ctx->db_xy_heading : nullptr;
     for (int k = 0; k < 4; ++k) mask.q[k] = base_pose ? base_pose[3 + k] : (k == 3 ? 1.0 : 0.0);
     mask.cos_tol = heading_cos_tol_host(ctx);
+    mask.elig = ctx->elig; mask.elig_n = ctx->elig_n; mask.elig_min = ctx->prm.min_matches; mask.elig_cap = ELIG_CAP;
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                         ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0, &mask);
