@@ -155,20 +155,26 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
     """Strong scaling of the whole-database search (BASELINE config 4): every rank sees every frame, owns 1/world of the
     records; frames go through in batches of 8 with two small all-gathers per batch."""
     from nclt_slam_project_amd.engine import Engine
-    from nclt_slam_project_amd.sharded import HipShard, ShardedRelocalizer
+    from nclt_slam_project_amd.sharded import DeviceShardedRelocalizer, HipShard, ShardedRelocalizer
     e = Engine(local_rank, W, H, 2048)
     frames, db, base_poses = build_workload(e, args.records, args.rows, 8)
     BATCH = 8
     shard = HipShard(e, *db, rank=rank, world=world, w=W, h=H, n_slots=BATCH)
     dev = None if (dist is None or args.backend != "nccl") else torch.device("cuda", local_rank)
-    sr = ShardedRelocalizer(shard, shard.base, rank, world, device=dev)
+    if world == 1 or args.backend == "nccl":
+        # exchange resident in HBM: top-k lists, merge, candidate hand-over and result records never visit the host
+        sr = DeviceShardedRelocalizer(shard, rank, world, torch.device("cuda", local_rank))
+        sr_tick = lambda fr, bp, seeds: sr.tick_batch(fr, bp, seeds)
+    else:
+        hr = ShardedRelocalizer(shard, shard.base, rank, world, device=dev)
+        sr_tick = lambda fr, bp, seeds: hr.tick_batch(fr, bp, seeds=seeds)
     frames_dev = [e.to_device(f) for f in frames]
     B = max(BATCH, args.frames_per_step // BATCH * BATCH)
 
     def step(s0):
         out = None
         for i in range(0, B, BATCH):
-            out = sr.tick_batch(frames_dev, base_poses, seeds=[s0 + i + j for j in range(BATCH)])[-1]
+            out = sr_tick(frames_dev, base_poses, [s0 + i + j for j in range(BATCH)])[-1]
         return out
 
     for w_ in range(args.warmup):
@@ -215,7 +221,8 @@ def bench_matrix(args, rank, world, local_rank, dist, torch):
     rng = np.random.default_rng(SEED + 4)
     A = rng.integers(0, 256, (F, 32), dtype=np.uint8)
     Bm = rng.integers(0, 256, (K, 32), dtype=np.uint8)
-    r0, r1 = rank * F // world, (rank + 1) * F // world
+    from nclt_slam_project_amd.sharded import matrix_row_block
+    r0, r1 = matrix_row_block(F, rank, world)
     a = e.to_device(A[r0:r1]); b = e.to_device(Bm)
     out = e.dev_alloc((r1 - r0) * K * 2)
     for _ in range(max(args.warmup, 1)):

@@ -460,6 +460,11 @@ __device__ double lm_normal_wave(const float *obj, const float *img, const int32
         }
         cost += ru * ru + rv * rv;
     }
+#if defined(RELOC_PNP_SUM28) && RELOC_PNP_SUM28 == 0          // developer switch: the r1 form, one butterfly per value
+    for (int k = 0; k < 21; ++k) H[k] = wave_sum(H[k]);
+    for (int k = 0; k < 6; ++k) g[k] = wave_sum(g[k]);
+    return wave_sum(cost);
+#endif
     // 28 wave-wide sums at once (see wave_sum28): ~130 VALU instructions instead of 28 x 30
     double v[32], tot[28];
     for (int k = 0; k < 21; ++k) v[k] = H[k];

@@ -391,6 +391,21 @@ class Engine:
                                               C.c_void_p(self._topk_dev), C.c_void_p(self._topk_dev + 128), int(k)),
                 "reloc_tick_scan_dev")
 
+    def tick_scan_into(self, img_dev: int, w: int, h: int, base_pose, k: int, ids_dev: int, counts_dev: int, nfeat_dev: int,
+                       order_rgb=False):
+        """ORB + shard scan + local top-k, everything left in caller-owned device memory (k ids, k counts, 1 feature count);
+        enqueue only"""
+        bp = None if base_pose is None else np.ascontiguousarray(base_pose, np.float64).reshape(7)
+        N.check(self._lib.reloc_tick_scan_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
+                                              C.c_void_p(ids_dev), C.c_void_p(counts_dev), int(k)), "reloc_tick_scan_dev")
+        self.d2d(nfeat_dev, int(self._lib.reloc_frame_count_dev(self._ctx)), 4)
+
+    def tick_solve_from(self, cand_ids_dev: int, n: int, base_pose, check_consistency: bool, seed: int = 0):
+        """matches + PnP + gates for the LOCAL record ids listed in device memory (-1 entries skipped); enqueue only"""
+        bp = np.ascontiguousarray(base_pose, np.float64).reshape(7)
+        N.check(self._lib.reloc_tick_solve_dev(self._ctx, C.c_void_p(cand_ids_dev), int(n), N.ptr(bp), int(check_consistency),
+                                               int(seed)), "reloc_tick_solve_dev")
+
     def tick_scan_fetch(self, k: int = 25):
         """(local record ids (k,), counts (k,), n_features) of the last enqueued scan, -1 / 0 padded (synchronises the stream)."""
         buf = np.empty(64, np.int32); nf = np.empty(1, np.int32)

@@ -33,6 +33,12 @@ def merge_topk(all_ids, all_counts, k=K_GLOBAL):
     return ids[order][:k], cnt[order][:k]
 
 
+def matrix_row_block(n_rows: int, rank: int, world: int):
+    """BASELINE.json config 5 (all-frames x all-keyframes distance matrix): rank r writes rows [a, b) of the matrix into
+    its own HBM; the keyframe descriptors are replicated, nothing is exchanged."""
+    return rank * n_rows // world, (rank + 1) * n_rows // world
+
+
 class ShardedRelocalizer:
     """backend: an object with
          scan(frame, base_pose, k, slot) -> (local ids (k,), counts (k,)) padded with -1 / 0
@@ -176,3 +182,132 @@ class HipShard:
     def close(self):
         for e in self.engines[1:]:
             e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device-resident exchange (one rank per GPU over RCCL): top-k lists, merge, candidate hand-over and result records stay
+# in HBM; the host sees ONE small copy per batch, at the end.  torch is plumbing here: device buffers, the collective
+# and a handful of tiny elementwise / top-k launches on its stream; every kernel of the path itself is the library's.
+def merge_topk_tensor(all_scan, k: int, base: int, n_local: int):
+    """all_scan: int32 tensor (W, B, 2k + 2) = per rank and frame [k global ids (-1 padded), k counts, n_features, pad].
+    Returns (win_gid (B, k) int32 global ids in rank order, -1 padded; cand_local (B, k) int32 local ids of the winners
+    this rank owns, -1 elsewhere; n_feat (B,) int32).  Same order as merge_topk: count desc, global id desc."""
+    import torch
+    W, B, _ = all_scan.shape
+    gid = all_scan[:, :, :k].permute(1, 0, 2).reshape(B, W * k).to(torch.int64)
+    cnt = all_scan[:, :, k:2 * k].permute(1, 0, 2).reshape(B, W * k).to(torch.int64)
+    key = torch.where(gid >= 0, (cnt << 32) | (gid + 1), torch.zeros_like(gid))       # unique per record; 0 = padding
+    top = torch.topk(key, min(k, W * k), dim=1, largest=True, sorted=True).values
+    if top.shape[1] < k:
+        top = torch.cat([top, torch.zeros(B, k - top.shape[1], dtype=top.dtype, device=top.device)], 1)
+    win_gid = torch.where(top > 0, (top & 0xFFFFFFFF) - 1, torch.full_like(top, -1)).to(torch.int32)
+    mine = (win_gid >= base) & (win_gid < base + n_local)
+    cand_local = torch.where(mine, win_gid - base, torch.full_like(win_gid, -1)).contiguous()
+    n_feat = all_scan[:, :, 2 * k].max(dim=0).values
+    return win_gid.contiguous(), cand_local, n_feat
+
+
+def pick_results(res_all: np.ndarray, win_gid: np.ndarray, n_feat: np.ndarray, bases, min_features=MIN_FEATURES):
+    """res_all: (W, B, 96) uint8 TickResult records of every rank; win_gid (B, k); bases: first global id of every rank.
+    The anchor of a frame = most inliers, earliest position in the global candidate order on ties (M:379)."""
+    W, B, _ = res_all.shape
+    f64 = res_all.view(np.float64).reshape(W, B, 12)
+    i32 = res_all.view(np.int32).reshape(W, B, 24)
+    out = []
+    for i in range(B):
+        n_cand = int((win_gid[i] >= 0).sum())
+        none = dict(n_inliers=0, reproj=0.0, anchor_pose=np.zeros(7), lm_idx=-1, n_candidates=n_cand)
+        if n_feat[i] < min_features:
+            out.append(dict(outcome=1, **{**none, "n_candidates": 0}))
+            continue
+        best = None
+        for r in range(W):
+            oc, n_inl, lm = int(i32[r, i, 18]), int(i32[r, i, 16]), int(i32[r, i, 17])
+            if oc not in (0, 4) or lm < 0:
+                continue
+            g = lm + int(bases[r])
+            pos = int(np.nonzero(win_gid[i] == g)[0][0])
+            if best is None or (n_inl, -pos) > (best[0], -best[1]):
+                best = (n_inl, pos, r, g, oc)
+        if best is None:
+            out.append(dict(outcome=3 if n_cand else 2, **none))
+            continue
+        n_inl, pos, r, g, oc = best
+        out.append(dict(outcome=oc, n_inliers=n_inl, reproj=float(np.float32(f64[r, i, 7])), anchor_pose=f64[r, i, :7].copy(),
+                        lm_idx=g, n_candidates=n_cand))
+    return out
+
+
+class DeviceShardedRelocalizer:
+    """tick_batch of ShardedRelocalizer with the exchange on the device.  shard: HipShard with >= B slots; device: the
+    torch device of this rank; group / world as for torch.distributed (world 1: no collective)."""
+
+    def __init__(self, shard: "HipShard", rank: int, world: int, device, group=None, k: int = K_GLOBAL, bases=None):
+        import torch
+        self.torch, self.shard, self.rank, self.world, self.device, self.group, self.k = torch, shard, rank, world, device, group, k
+        B = len(shard.engines)
+        self.B = B
+        self.scan_buf = torch.full((B, 2 * k + 2), -1, dtype=torch.int32, device=device)
+        self.res_buf = torch.zeros((B, 96), dtype=torch.uint8, device=device)
+        self.all_scan = torch.empty((world, B, 2 * k + 2), dtype=torch.int32, device=device)
+        self.all_res = torch.empty((world, B, 96), dtype=torch.uint8, device=device)
+        self.exch = torch.cuda.Stream(device=device)
+        self.ext = [torch.cuda.ExternalStream(e.stream_ptr, device=device) for e in shard.engines]
+        if bases is None:
+            if world == 1:
+                bases = [shard.base]
+            else:
+                import torch.distributed as dist
+                t = torch.tensor([shard.base], dtype=torch.int64, device=device)
+                allb = torch.empty(world, dtype=torch.int64, device=device)
+                dist.all_gather_into_tensor(allb, t, group=group)
+                bases = allb.cpu().tolist()
+        self.bases = list(bases)
+
+    def tick_batch(self, frames_dev, base_poses, seeds=None):
+        torch, sh, k, B = self.torch, self.shard, self.k, len(frames_dev)
+        if B > self.B:
+            raise ValueError(f"batch of {B} frames on a shard with {self.B} slots")
+        seeds = list(seeds) if seeds is not None else [0] * B
+        es = sh.engines
+        sb = self.scan_buf
+        row = sb.stride(0) * 4
+        if sh.n_records:
+            for i in range(B):                                        # ORB + shard scan + local top-k, one stream per frame
+                p = sb.data_ptr() + i * row
+                es[i].tick_scan_into(frames_dev[i], sh.w, sh.h, base_poses[i], k, p, p + 4 * k, p + 8 * k)
+        with torch.cuda.stream(self.exch):
+            for i in range(B):
+                self.exch.wait_stream(self.ext[i])
+            if sh.n_records:
+                ids = sb[:, :k]
+                sb[:, :k] = torch.where(ids >= 0, ids + sh.base, ids)              # local -> global ids
+            else:
+                sb[:, :k] = -1; sb[:, k:2 * k] = 0; sb[:, 2 * k] = -1
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self.all_scan, sb, group=self.group)  # B x (2k + 2) ints per rank
+                all_scan = self.all_scan
+            else:
+                all_scan = sb[None]
+            win_gid, cand_local, n_feat = merge_topk_tensor(all_scan[:, :B], k, sh.base, sh.n_records)
+        if sh.n_records:
+            for i in range(B):                                        # owners solve; a rank without a winner finishes at once
+                self.ext[i].wait_stream(self.exch)
+                es[i].tick_solve_from(cand_local.data_ptr() + i * k * 4, k, base_poses[i], False, seeds[i])
+                es[i].d2d(self.res_buf.data_ptr() + i * 96, es[i].tick_result_dev, 96)
+        with torch.cuda.stream(self.exch):
+            for i in range(B):
+                self.exch.wait_stream(self.ext[i])
+            if not sh.n_records:
+                self.res_buf.zero_()
+                self.res_buf.view(torch.int32)[:, 18] = 2             # outcome no_candidates, never picked
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self.all_res, self.res_buf, group=self.group)
+                all_res = self.all_res
+            else:
+                all_res = self.res_buf[None]
+            host = (all_res[:, :B].cpu().numpy(), win_gid.cpu().numpy(), n_feat.cpu().numpy())   # the one trip to the host
+        self._keep = (cand_local, win_gid)                            # alive until the streams have passed them
+        return pick_results(host[0], host[1], host[2], self.bases)

@@ -146,6 +146,28 @@ def test_config4_batch_of_8_on_100k_records(engine, oracle, config4):
     assert counts[top[0]] == counts.max() and len(top) >= 1
 
 
+def test_config4_device_resident_exchange(engine, config4):
+    """the same 8-frame batch with the exchange kept on the device (DeviceShardedRelocalizer: scan results written into
+    a torch buffer, global ids / merge / candidate hand-over by tiny torch ops, owners solve from device-resident lists,
+    result records gathered on the device, ONE copy to the host per batch) == the unsharded tick"""
+    import torch
+    from nclt_slam_project_amd.sharded import DeviceShardedRelocalizer, HipShard
+    frames, db, base_poses, ref = config4
+    desc, pts, off, poses = db
+    shard = HipShard(engine, desc, pts, off, poses, rank=0, world=1, n_slots=8)
+    sr = DeviceShardedRelocalizer(shard, 0, 1, torch.device("cuda", 0))
+    fdev = [engine.to_device(f) for f in frames]
+    for rep in range(2):                                  # twice: buffers and streams are reused between batches
+        res = sr.tick_batch(fdev, base_poses, seeds=[100 + f for f in range(8)])
+        for got, (exp, dbg) in zip(res, ref):
+            assert got["outcome"] == exp["outcome"] and got["n_inliers"] == exp["n_inliers"] and got["lm_idx"] == exp["lm_idx"]
+            assert got["n_candidates"] == exp["n_candidates"]
+            np.testing.assert_allclose(got["anchor_pose"], exp["anchor_pose"], atol=1e-9)
+    for p in fdev:
+        engine.dev_free(p)
+    shard.close()
+
+
 class _InProcessGroup:
     """stands in for a process group when the ranks are threads of one process (one GPU): all_gather with a barrier"""
 
