@@ -78,9 +78,6 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->tick_res, 1);
     rc |= dalloc(&c->accum_res, 1);
     rc |= dalloc(&c->tick_flags, 4);
-    rc |= dalloc(&c->elig, ELIG_CAP);
-    rc |= dalloc(&c->elig_n, 1);
-    if (rc == 0 && hipMemset(c->elig_n, 0, 4) != hipSuccess) rc = RELOC_E_HIP;
     rc |= dalloc(&c->scan_ticket, 9 * 32);
     if (rc == 0 && hipMemset(c->scan_ticket, 0, 9 * 32 * 4) != hipSuccess) rc = RELOC_E_HIP;
     return rc;
@@ -157,7 +154,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
                     c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off,
                     c->db_pose, c->db_xy_heading, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,
                     c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
-                    c->p_out, c->tick_res, c->accum_res, c->tick_flags, c->scan_ticket, c->elig, c->elig_n};
+                    c->p_out, c->tick_res, c->accum_res, c->tick_flags, c->scan_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     {   // the database that is not selected

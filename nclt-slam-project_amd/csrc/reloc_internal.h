@@ -45,7 +45,6 @@ constexpr int NLEV = RELOC_ORB_NLEVELS;
 constexpr int MAX_REC_ROWS = 4096;   // largest record (teach rows) the fused scan accepts
 constexpr int MAX_CAND = 32;         // PnP candidates per tick (5 local / 25 global)
 constexpr int MAX_HYP = 1024;        // RANSAC hypotheses per candidate (iterationsCount)
-constexpr int ELIG_CAP = 4096;       // eligible-record keys kept per scan
 constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps the record index in 20 bits
 
 struct OrbLevel {
@@ -187,11 +186,6 @@ struct ScanMask {
     double q[4];
     double cos_tol = 6.123233995736766e-17;      // cos(HEADING_TOL_DEG = 90 degrees) in double
     const int32_t *skip_if = nullptr;            // RELOC_TICK_AUTO: the whole launch stands down when *skip_if != 0
-    // eligible list (counts mode): every record with at least elig_min mutual matches also leaves its ranking key
-    // (count << 32 | id + 1) in an unordered list, so the candidate ranking reads a handful of keys instead of L counts
-    unsigned long long *elig = nullptr;
-    int32_t *elig_n = nullptr;
-    int elig_min = 0, elig_cap = 0;
     // emit mode only (M:333-336): when g_obj is set, every mutual match also leaves its 3-D / 2-D pair
     // (keypoints_3d_cam[queryIdx], pts_curr_2d[trainIdx]) next to its index triplet, so no gather launch follows
     const float *g_pts3d = nullptr, *g_xy = nullptr;
@@ -266,8 +260,6 @@ struct reloc_ctx {
     int32_t *db_counts = nullptr;    // L per-record mutual counts
     unsigned long long *topk_part = nullptr;   // per-block winners of the two-stage top-k (topk_blocks x 32)
     int topk_blocks = 0;
-    unsigned long long *elig = nullptr; // ELIG_CAP ranking keys of the last whole-database scan (see ScanMask)
-    int32_t *elig_n = nullptr;          // 1: keys offered (may exceed ELIG_CAP: then the ranking walks the counts instead)
     AccumResult *accum_res = nullptr;   // 1
     int32_t *tick_flags = nullptr;      // [0] relocating flag of the current tick
 

@@ -449,10 +449,6 @@ __device__ __forceinline__ void db_scan_body(
         if (tid == 0) {
             if (counts) counts[EMIT ? it : r] = (int32_t)base;
             if (EMIT && m_n) m_n[it] = (int32_t)base;
-            if (!EMIT && mask.elig && (int)base >= mask.elig_min) {
-                const int p = atomicAdd(mask.elig_n, 1);
-                if (p < mask.elig_cap) mask.elig[p] = ((unsigned long long)base << 32) | (unsigned)(r + 1);
-            }
         }
         advance();
     }
@@ -579,6 +575,77 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few current descriptors (C <= 64): the roles swap.  With one or a few dozen queries the column-per-lane kernel
+// above wastes its 128 lanes x columns (Q = 1 and Q = 32 both cost the 128-column price, 55 us at 10 000 x 64); here a
+// LANE is a teach row -- the wave reads 64 rows of the record straight from HBM (2 KB, coalesced), the queries are
+// wave-uniform and arrive through the scalar cache -- so the work follows C and the kernel runs at the pace of the
+// database read.  Per 64-row chunk and query: 16 instructions of distance, the row's running best (lane-local key
+// distance << 6 | query: lowest query index on ties), and the query's best row over the 64 lanes, taken 16 queries at
+// a time by the register-tile butterfly rows_min<16> (about 4 instructions per query instead of a 12-instruction wave
+// reduction each).  One wave owns a record (no barriers); its 64 column minima and the record's row keys live in the
+// wave's slice of LDS.  Records of more than SQ_MAX_ROWS rows, emit mode and the heading mask stay with k_db_scan.
+constexpr int SQ_MAX_ROWS = 1024;
+constexpr int SQ_WAVES = 4;
+
+// G = queries per butterfly group (4, 8 or 16): a call with 1-4 queries evaluates 4 distances per row, not 16
+template <int G>
+__global__ __launch_bounds__(64 * SQ_WAVES) void k_db_scan_rows(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
+                                                                const uint4 *__restrict__ cur, const int32_t *__restrict__ n_cur_p,
+                                                                int n_cur_max, int32_t *__restrict__ counts)
+{
+    __shared__ u32 s_col[SQ_WAVES][64];                 // per query: distance << 16 | row of the best row so far
+    __shared__ unsigned short s_row[SQ_WAVES][SQ_MAX_ROWS];   // per row: distance << 6 | query of the best query
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
+    u32 *col = s_col[wave];
+    unsigned short *rowk = s_row[wave];
+    const int gw = blockIdx.x * SQ_WAVES + wave, nw = gridDim.x * SQ_WAVES;
+    for (int r = gw; r < n_rec; r += nw) {
+        const int64_t row0 = off[r];
+        const int n = (int)(off[r + 1] - row0);
+        if (n <= 0 || C <= 0) { if (lane == 0) counts[r] = 0; continue; }
+        col[lane] = 0xFFFFFFFFu;
+        for (int tc = 0; tc < n; tc += 64) {
+            const int row = min(tc + lane, n - 1);      // lanes past the end repeat the last row: a duplicate with a larger index never wins
+            const uint4 a = db[2 * (row0 + row)], b = db[2 * (row0 + row) + 1];
+            const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            u32 rbest = 0xFFFFFFFFu;
+            for (int q0 = 0; q0 < C; q0 += G) {
+                u32 ck[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int q = min(q0 + j, C - 1);   // wave-uniform; repeats of the last query lose every tie (larger index)
+                    const uint4 qa = cur[2 * q], qb = cur[2 * q + 1];        // scalar loads
+                    u32 h = 0;
+                    h = bcnt_acc(w[0] ^ qa.x, h); h = bcnt_acc(w[1] ^ qa.y, h); h = bcnt_acc(w[2] ^ qa.z, h); h = bcnt_acc(w[3] ^ qa.w, h);
+                    h = bcnt_acc(w[4] ^ qb.x, h); h = bcnt_acc(w[5] ^ qb.y, h); h = bcnt_acc(w[6] ^ qb.z, h); h = bcnt_acc(w[7] ^ qb.w, h);
+                    rbest = umin(rbest, (h << 6) | (u32)(q0 + j));
+                    ck[j] = (h << 6) | (u32)lane;
+                }
+                const u32 m = rows_min<G>(ck, lane);    // lane l: best (distance, lane) of query q0 + (l & (G - 1)) over the 64 rows
+                if (lane < G && q0 + lane < C) {
+                    const u32 key = ((m >> 6) << 16) | (u32)(tc + (int)(m & 63u));
+                    if (key < col[q0 + lane]) col[q0 + lane] = key;          // one wave: plain read-modify-write
+                }
+            }
+            if (tc + lane < n) rowk[tc + lane] = (unsigned short)rbest;
+        }
+        // mutual pairs: row r's best query must name r as its best row (lowest index on ties both ways)
+        int total = 0;
+        for (int tc = 0; tc < n; tc += 64) {
+            bool mutual = false;
+            if (tc + lane < n) {
+                const u32 k = rowk[tc + lane];
+                mutual = (col[k & 63u] & 0xFFFFu) == (u32)(tc + lane);
+            }
+            total += __popcll(__ballot(mutual));
+        }
+        if (lane == 0) counts[r] = total;
+    }
+}
+
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
@@ -592,6 +659,19 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (n_cur_max > 65535) { reloc_set_error("db scan: more than 65535 current descriptors"); return RELOC_E_CAPACITY; }
     if (max_rows > MAX_REC_ROWS) { reloc_set_error("db scan: record larger than %d rows", MAX_REC_ROWS); return RELOC_E_CAPACITY; }
     if (max_rows < 1) max_rows = 1;
+    if (!m_qidx && !rec_ids && !n_ids_dev && !mask.xyh && counts && n_cur_max <= 64 && max_rows <= SQ_MAX_ROWS) {
+        // few queries: lane = teach row (k_db_scan_rows)
+        int grid = ctx->num_cu * 8;                        // 8 workgroups of 4 waves per CU
+        const int need = (n_ids_max + SQ_WAVES - 1) / SQ_WAVES;
+        if (grid > need) grid = need;
+#define RELOC_LAUNCH_ROWS(G)                                                                                                  \
+    hipLaunchKernelGGL(k_db_scan_rows<G>, dim3(grid), dim3(64 * SQ_WAVES), 0, ctx->stream, (const uint4 *)db_desc, db_off, n_ids_max, \
+                       (const uint4 *)cur, n_cur_dev, n_cur_max, counts)
+        if (n_cur_max <= 4) RELOC_LAUNCH_ROWS(4); else if (n_cur_max <= 8) RELOC_LAUNCH_ROWS(8); else RELOC_LAUNCH_ROWS(16);
+#undef RELOC_LAUNCH_ROWS
+        HIP_TRY(hipGetLastError());
+        return RELOC_OK;
+    }
     const int nj = n_cur_max <= 128 ? 2 : (n_cur_max <= 256 ? 4 : 8);      // columns per lane, see k_db_scan
     const int cb = 64 * nj;
     const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;

@@ -150,7 +150,7 @@ __device__ int block_topk(int begin, int end, int k, KeyFn keyfn, unsigned long 
 //     its top 44 bits order the candidates (ties at that resolution, < 1e-9 relative, fall back to the
 //     lower index), the radius test itself uses the exact distance.
 //   global mode (G:329-344): top-k of (count, id) descending among the records with count >= MIN_MATCHES
-//     (the scan leaves count 0 on heading-incompatible records, see ScanMask).
+//     (the scan leaves count 0 on heading-incompatible records, see ScanMask): k_topk_counts, a histogram selection.
 constexpr int TOPK_SLICE = 1024;
 
 struct LocalKey {
@@ -163,21 +163,6 @@ struct LocalKey {
         const unsigned long long q = (unsigned long long)__double_as_longlong(d) >> 20;
         return ((0xFFFFFFFFFFFull - q) << 20) | (unsigned long long)(0xFFFFF - (i & 0xFFFFF));   // nearer, then lower index
     }
-};
-
-struct CountKey {
-    const int32_t *counts;
-    int min_matches;
-    __device__ unsigned long long operator()(int i) const
-    {
-        const int c = counts[i];
-        return c < min_matches ? 0ull : ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
-    }
-};
-
-struct ListKey {
-    const unsigned long long *keys;
-    __device__ unsigned long long operator()(int i) const { return keys[i]; }
 };
 
 struct PartKey {
@@ -231,39 +216,110 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *_
     }
 }
 
+// Candidate ranking of the whole-database search (G:342-343: `scored.sort(reverse=True)[:25]` on (count, id) tuples):
+// the k largest (count, id) among the records with count >= min_matches, in descending order.
+// Counts take few distinct values (0 .. rows of the largest record) and cluster -- cross-checked matching of a 64-row
+// record against 500 descriptors leaves ~57 +- 3 mutual pairs even on unrelated data, so nearly every record passes
+// MIN_MATCHES and the winners are separated by ties -- which makes this a histogram selection, not a sort: one block
+//   1. histograms the counts in LDS,
+//   2. walks the bins from the top to the count c* that holds the k-th winner (records above c* all win),
+//   3. takes the records above c* and, among those AT c*, the ones with the largest ids: every thread owns a contiguous
+//      id range, a block-wide suffix sum of the per-thread tie counts tells it how many ties rank before its own,
+//   4. orders the <= k winners with one wave.
+// Two passes over L counts and no dependent chain of k reductions per slice (r1: 10 slice blocks x 50 chained wave
+// reductions + a merge kernel = 23 us at L = 10 000; measured r2 in profiles/).
 // skip_if: RELOC_TICK_AUTO -- the local search found candidates (*skip_if != 0): they stand, nothing is ranked (the scan
-// before this kernel has skipped itself the same way).  relocating: set when the whole-database ranking produced the list.
-__global__ __launch_bounds__(TICK_BLOCK) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base, int min_matches,
-                                                            const unsigned long long *__restrict__ part, int n_blocks,
-                                                            int32_t *__restrict__ out_ids, int32_t *__restrict__ out_counts,
-                                                            int32_t *__restrict__ out_n, const int32_t *skip_if,
-                                                            int32_t *__restrict__ relocating,
-                                                            const unsigned long long *__restrict__ elig, int32_t *elig_n, int elig_cap)
+// before this kernel has skipped itself the same way).  relocating: set when this ranking produced the list.
+constexpr int TOPK_HIST_THREADS = 1024;
+__global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base,
+                                                                   int min_matches, int max_count, int32_t *__restrict__ out_ids,
+                                                                   int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n,
+                                                                   const int32_t *skip_if, int32_t *__restrict__ relocating)
 {
-    __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
-    __shared__ unsigned long long s_keys[TOPK_MAX + 1];
-    if (skip_if && *skip_if != 0) return;                       // block-uniform; out_n (may alias skip_if) is written last
-    // the scan has left the keys of the records with >= min_matches mutual matches in `elig` (normally a handful): rank
-    // those; only when more than elig_cap records qualified (elig_n counts all offers) walk the counts themselves
-    int n;
-    const int n_elig = elig ? *elig_n : -1;
-    if (n_elig >= 0 && n_elig <= elig_cap) n = block_topk(0, n_elig, k, ListKey{elig}, s_red, s_keys);
-    else n = topk_final(CountKey{counts, min_matches}, L, k, part, n_blocks, s_red, s_keys);
+    extern __shared__ int s_hist[];                     // max_count + 2 bins
+    __shared__ int s_wave[16];
+    __shared__ int s_cstar, s_above, s_nlist;
+    __shared__ unsigned long long s_list[TOPK_MAX];
+    if (skip_if && *skip_if != 0) return;               // block-uniform; out_n (may alias skip_if) is written last
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i <= max_count + 1; i += TOPK_HIST_THREADS) s_hist[i] = 0;
+    if (tid == 0) s_nlist = 0;
     __syncthreads();
-    const int tid = threadIdx.x;
-    if (tid < k) {
-        if (tid < n) {
-            out_ids[tid] = (int32_t)((unsigned)(s_keys[tid] & 0xFFFFFFFFu) - 1) + id_base;
-            if (out_counts) out_counts[tid] = (int32_t)(s_keys[tid] >> 32);
-        } else {
-            out_ids[tid] = -1;
-            if (out_counts) out_counts[tid] = 0;
+    const int chunk = (L + TOPK_HIST_THREADS - 1) / TOPK_HIST_THREADS;
+    const int lo = min(tid * chunk, L), hi = min(lo + chunk, L);          // this thread's ids, ascending
+    for (int i = lo; i < hi; ++i) {
+        const int c = min(counts[i], max_count + 1);
+        if (c >= min_matches) atomicAdd(&s_hist[c], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // bins from the top, 64 at a time: first bin (descending) at which the running total reaches k
+        int above = 0, cstar = -1;
+        for (int top = max_count + 1; top >= min_matches && cstar < 0; top -= 64) {
+            const int bin = top - lane;                                    // lane 0 = highest bin of this group
+            const int h = bin >= min_matches ? s_hist[bin] : 0;
+            int incl = h;                                                  // inclusive prefix over lanes 0..lane
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const unsigned long long hit = __ballot(above + incl >= k && bin >= min_matches);
+            if (hit) {
+                const int l0 = __ffsll((long long)hit) - 1;
+                cstar = top - l0;
+                above += __shfl(incl, l0) - __shfl(h, l0);
+            } else {
+                above += __shfl(incl, 63);
+            }
+        }
+        if (lane == 0) { s_cstar = cstar; s_above = above; }              // cstar < 0: fewer than k eligible records, all win
+    }
+    __syncthreads();
+    const int cstar = s_cstar, need = cstar < 0 ? 0 : k - s_above;         // ties at c* still wanted
+    int ties = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int c = min(counts[i], max_count + 1);
+        if (c < min_matches) continue;
+        if (c > cstar || cstar < 0) {
+            const int p = atomicAdd(&s_nlist, 1);
+            if (p < TOPK_MAX) s_list[p] = ((unsigned long long)(unsigned)c << 32) | (unsigned)(i + 1);
+        } else if (c == cstar) {
+            ++ties;
         }
     }
-    if (tid == 0) {
-        *out_n = n;
-        if (relocating) *relocating = 1;
-        if (elig) *elig_n = 0;                                   // ready for the next scan on this stream
+    // ties ranking before this thread's = ties owned by threads with larger ids
+    int incl = ties;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_down(incl, d); if (lane + d < 64) incl += o; }   // suffix within the wave
+    if (lane == 0) s_wave[wave] = incl;
+    __syncthreads();
+    int after = incl - ties;
+    for (int w = wave + 1; w < TOPK_HIST_THREADS / 64; ++w) after += s_wave[w];
+    if (ties && after < need) {
+        int take = min(ties, need - after);
+        for (int i = hi - 1; i >= lo && take > 0; --i) {
+            if (min(counts[i], max_count + 1) == cstar) {
+                const int p = atomicAdd(&s_nlist, 1);
+                if (p < TOPK_MAX) s_list[p] = ((unsigned long long)(unsigned)cstar << 32) | (unsigned)(i + 1);
+                --take;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = min(s_nlist, k);
+    if (wave == 0) {
+        // descending order by rank counting: keys are unique
+        const unsigned long long mine = lane < n ? s_list[lane] : 0ull;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += s_list[j] > mine;
+        if (lane < n) {
+            out_ids[rank] = (int32_t)((unsigned)(mine & 0xFFFFFFFFu) - 1) + id_base;
+            if (out_counts) out_counts[rank] = (int32_t)(mine >> 32);
+        }
+        if (lane >= n && lane < k) {
+            out_ids[lane] = -1;
+            if (out_counts) out_counts[lane] = 0;
+        }
+        if (lane == 0) {
+            *out_n = n;
+            if (relocating) *relocating = 1;
+        }
     }
 }
 
@@ -279,19 +335,15 @@ static void launch_candidates_local(reloc_ctx *ctx, const TickParams &prm)
                        ctx->cand_ids, ctx->cand_n, ctx->tick_flags);
 }
 
-// auto_mode: the ranking only takes effect when the local search left no candidate (see k_topk_counts); the slice
-// kernel is harmless either way (it only writes topk_part)
+// auto_mode: the ranking only takes effect when the local search left no candidate (see k_topk_counts)
 static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts, bool auto_mode)
 {
     const int L = (int)ctx->db_records;
-    const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
-    const int mm = ctx->prm.min_matches;
-    // the scan of this tick has listed the eligible records (scan_mask_elig): one launch ranks them.  In the rare
-    // overflow case the same kernel walks all L counts with one block (n_blocks = 0): slow, but exact.
-    (void)nb;
-    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_counts, L, k, 0, mm, ctx->topk_part, 0,
-                       out_ids, out_counts, ctx->cand_n, auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr,
-                       ctx->tick_flags, ctx->elig, ctx->elig_n, ELIG_CAP);
+    // a count cannot exceed the rows of the largest record nor the features of a frame
+    const int max_count = ctx->db_max_rows < ctx->max_feat ? ctx->db_max_rows : ctx->max_feat;
+    hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TOPK_HIST_THREADS), (size_t)(max_count + 2) * sizeof(int), ctx->stream, ctx->db_counts,
+                       L, k, 0, ctx->prm.min_matches, max_count, out_ids, out_counts, ctx->cand_n,
+                       auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr, ctx->tick_flags);
 }
 
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
@@ -444,7 +496,6 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
         for (int k = 0; k < 4; ++k) mask.q[k] = base_pose[3 + k];
         mask.cos_tol = prm.cos_tol;
         mask.skip_if = mode == RELOC_TICK_AUTO ? ctx->cand_n : nullptr;
-        mask.elig = ctx->elig; mask.elig_n = ctx->elig_n; mask.elig_min = ctx->prm.min_matches; mask.elig_cap = ELIG_CAP;
         reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
         rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                             ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
@@ -517,7 +568,6 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
     mask.xyh = base_pose ? ctx->db_xy_heading : nullptr;
     for (int k = 0; k < 4; ++k) mask.q[k] = base_pose ? base_pose[3 + k] : (k == 3 ? 1.0 : 0.0);
     mask.cos_tol = heading_cos_tol_host(ctx);
-    mask.elig = ctx->elig; mask.elig_n = ctx->elig_n; mask.elig_min = ctx->prm.min_matches; mask.elig_cap = ELIG_CAP;
     reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
                         ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0, &mask);

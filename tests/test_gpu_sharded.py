@@ -76,3 +76,35 @@ def test_topk_when_one_thread_owns_most_winners(engine, oracle):
     np.testing.assert_array_equal(ids[: len(exp)], exp)
     np.testing.assert_array_equal(cnt[: len(exp)], counts[exp])
     assert (ids[len(exp):] == -1).all()
+
+
+@pytest.mark.parametrize("k", [25, 5, 32])
+def test_candidate_ranking_with_massive_ties(engine, oracle, k):
+    """k_topk_counts is a histogram selection: the winners at the threshold count are picked by id.  Databases built
+    from a few distinct records repeated many times give hundreds of records with EQUAL counts; the list must still be
+    `sorted((count, id), reverse=True)[:k]` (G:342-343), also when fewer than k records reach MIN_MATCHES."""
+    rng = np.random.default_rng(101 + k)
+    img = synth.textured_frame(rng, 640, 480)
+    feat = engine.orb_detect_compute(engine.gray(img), 500)
+    protos = []
+    for rows, flip in ((40, 0.02), (40, 0.02), (24, 0.30), (8, 0.5)):      # two strong prototypes, one weak, one below MIN_MATCHES
+        src = rng.choice(feat["n"], rows, replace=False)
+        protos.append(synth.perturb_descriptors(rng, feat["desc"][src], flip))
+    for L, weights in ((3000, (0.3, 0.3, 0.3, 0.1)), (600, (0.0, 0.005, 0.0, 0.995)), (40, (0.0, 0.0, 0.0, 1.0))):
+        which = rng.choice(4, L, p=weights)
+        n = np.array([len(protos[w]) for w in which], np.int64)
+        off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
+        desc = np.concatenate([protos[w] for w in which])
+        pts = np.zeros((len(desc), 3), np.float32)
+        poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1))
+        engine.db_upload(desc, pts, off, poses)
+        frame_dev = engine.to_device(img)
+        ids, cnt, _ = engine.tick_scan(frame_dev, 640, 480, None, k=k)
+        engine.dev_free(frame_dev)
+        counts = oracle.db_match_counts(desc, off, feat["desc"])
+        exp = oracle.topk_records(counts, 10, k)
+        np.testing.assert_array_equal(ids[: len(exp)], exp)
+        np.testing.assert_array_equal(cnt[: len(exp)], counts[exp])
+        assert (ids[len(exp):] == -1).all() and (cnt[len(exp):] == 0).all()
+        if L == 3000:
+            assert len(exp) == k and len(set(counts[exp].tolist())) <= 2           # the winners really are a tie group
