@@ -44,7 +44,7 @@ def scan_cases(e):
             alg = 32 * T + 32 * Q + 4 * L
             out(case="db_scan", rows=str(rows), records=L, descriptors=T, Q=Q, us=round(us, 1),
                 pairs_per_s=T * Q / (us * 1e-6), algorithmic_GBps=alg / (us * 1e-6) / 1e9, hbm_frac=alg / (us * 1e-6) / 8e12,
-                note="128 columns per wave is the smallest shape: the cost is flat below Q = 128" if Q <= 128 else "")
+                note="lane = teach row kernel (k_db_scan_rows)" if Q <= 64 else "")
             e.dev_free(cur)
         e.dev_free(cnt)
 
