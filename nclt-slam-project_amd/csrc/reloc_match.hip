@@ -296,6 +296,10 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // mask.xyh != NULL: heading-incompatible records are not scored (count 0), see ScanMask.
 // NJ = 8 is the working point (500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per SIMD);
 // NJ = 4 / 2 serve calls with at most 256 / 128 current descriptors, see k_db_scan.  (NJ = 4 with two blocks and 8 waves per SIMD for 500 descriptors was measured slower, 188 vs 176 us.)
+// Measured and dropped in round 2 (same box, interleaved; profiles/r2_scan_variants.log, last group): the current
+// descriptors kept ONCE per workgroup in LDS (two conflict-free 16-byte planes) and streamed column by column against 4-8
+// teach rows held in SGPRs -- 58 VGPRs, 8 waves per SIMD, 512-thread workgroups, same 20 instructions per pair: 176 vs
+// 170 us at 10 000 records, 1533 vs 1497 us at 100 000.  Occupancy is not what holds this kernel back.
 template <int NJ, bool EMIT>
 __device__ __forceinline__ void db_scan_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
