@@ -360,3 +360,47 @@ def test_selftest_harness_passes_on_own_teach_frames(oracle):
     ok, s = selftest([(f, i) for i, f in enumerate(frames)], rec.database(), cv2)
     assert ok and s["n"] == 4 and s["n_within"] == 4
     assert all(r[0] == r[1] and r[2] > 100 for r in s["rows"])      # each frame picks its own record
+
+
+def test_row_grammar_and_std_mapping_against_a_reference_run_log():
+    """tests/golden/reference_run09_anchor_matches.csv is the anchor log the reference committed for one real repeat run
+    (simulation/isaac/experiments/76_rgbd_no_imu_ours/results/run_09/anchor_matches.csv, 680 ticks; data, copied as is).
+    Its images are not in the reference tree, so the run cannot be replayed; what it does pin: the row format the
+    analysis scripts parse, the outcome vocabulary, and -- row by row -- the inlier-count -> std mapping (M:400-405), the
+    shift in the outcome string (hypot of anchor - VIO, M:391), the 2-decimal error and the gates the rows respect."""
+    import math
+    import re
+    from nclt_slam_project_amd.matcher import TickOutcome
+    rows = open(os.path.join(GOLD, "reference_run09_anchor_matches.csv")).read().splitlines()
+    assert rows[0] + "\n" == CSV_HEADER and len(rows) == 681
+    cfg = MatcherConfig()
+    seen = {}
+    for line in rows[1:]:
+        ts, vx, vy, n_cand, n_inl, err, ax, ay, outcome = line.split(",")
+        n_cand, n_inl = int(n_cand), int(n_inl)
+        assert 0 <= n_cand <= cfg.max_candidates
+        kind = re.sub(r"[0-9.]+", "#", outcome)
+        seen[kind] = seen.get(kind, 0) + 1
+        if outcome.startswith("published"):
+            std = P.anchor_std(n_inl)
+            shift = math.hypot(float(ax) - float(vx), float(ay) - float(vy))
+            # the logged VIO position is rounded to 3 decimals, so the recomputed shift may sit 0.001 m off a rounding edge
+            assert outcome.startswith(f"published_std{std:.2f}_shift") and abs(float(outcome.split("shift")[1]) - shift) <= 0.051
+            assert n_inl >= cfg.min_inliers and float(err) <= cfg.reproj_max_px and shift <= cfg.consistency_m + 0.051
+            assert re.fullmatch(r"\d+\.\d\d", err)
+        elif outcome.startswith("consistency_fail"):
+            shift = math.hypot(float(ax) - float(vx), float(ay) - float(vy))
+            assert shift > cfg.consistency_m - 0.051 and abs(float(outcome[len("consistency_fail_"):-1]) - shift) <= 0.051
+        else:
+            assert outcome in ("no_candidates", "no_pnp_accept", "curr_no_features") and (ax, ay, err) == ("", "", "")
+            assert n_inl == 0 and (outcome != "no_candidates" or n_cand == 0)
+    assert seen == {"published_std#_shift#": 259, "no_pnp_accept": 306, "no_candidates": 87, "consistency_fail_#m": 28}
+    # and the product writes rows of exactly this shape
+    o = TickOutcome(1776895759.688, (71.086, -22.229), 3, 63, 0.85, (71.0405923836321, -22.15645049972106, 0, 0, 0, 0, 1),
+                    "published_std0.05_shift0.1")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        m = LandmarkMatcherCore.__new__(LandmarkMatcherCore)
+        m.log_csv = os.path.join(d, "a.csv")
+        m._csv(o)
+        assert open(m.log_csv).read().strip() == rows[1]
