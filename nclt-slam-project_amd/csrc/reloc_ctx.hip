@@ -132,7 +132,8 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_min_dist_m = RELOC_ACCUM_MIN_DIST_M;
     c->prm.accum_depth_min_m = RELOC_ACCUM_DEPTH_MIN_M;
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
-    if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switch
+    if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
+    if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
         return nullptr;

@@ -242,6 +242,7 @@ struct reloc_ctx {
     reloc_params prm;
     int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
+    int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
     uint32_t *scan_ticket = nullptr; // 8 per-XCD record counters + 1 exit counter, 128 bytes apart (k_db_scan ticket scheduling)
 
     // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----

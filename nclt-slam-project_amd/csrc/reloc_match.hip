@@ -305,7 +305,7 @@ __device__ __forceinline__ void db_scan_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
     int32_t *__restrict__ counts, int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, const ScanMask &mask, u32 *ticket)
+    int32_t *__restrict__ m_n, int emit_stride, const ScanMask &mask, u32 *ticket, int quota)
 {
     constexpr int CB = 64 * NJ;           // columns per block
     const int tid = threadIdx.x, lane = tid & 63;
@@ -368,13 +368,18 @@ __device__ __forceinline__ void db_scan_body(
         __syncthreads();
         it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
     }
+    // quota: a workgroup leaves after that many records although tickets remain (the grid then holds several
+    // generations): its slot goes to whatever waits -- with several contexts sharing the chip that is another stream's
+    // ORB / PnP kernel, which otherwise would not get a CU until this whole scan has drained
+    int left = quota > 0 ? quota : 0x7fffffff;
     for (; it < n_ids;) {
+        --left;
         u32 next_ticket = 0;
-        if (ticket && tid == 0) next_ticket = draw();
+        if (ticket && tid == 0 && left > 0) next_ticket = draw();        // no draw that this workgroup would not serve
         auto advance = [&]() {
             if (ticket) {
                 __syncthreads();
-                if (tid == 0) wsum[8] = (u32)settle(next_ticket);
+                if (tid == 0) wsum[8] = left > 0 ? (u32)settle(next_ticket) : (u32)n_ids;
                 __syncthreads();
                 it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
             } else {
@@ -474,12 +479,12 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
     int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket)
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota)
 {
     extern __shared__ u32 lds[];
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
     db_scan_body<NJ, EMIT>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
-                           emit_stride, mask, ticket);
+                           emit_stride, mask, ticket, quota);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -681,25 +686,34 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;
     const size_t lds = (size_t)(ncb * cb + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
-    // Whole-database scans (host-known record count, more records than resident workgroups) run ONE resident generation
-    // that draws records from a ticket counter: no tail of half-empty CUs while the last static generation drains, and
-    // the 16 KB-per-wave load of the current descriptors happens once per slot instead of once per workgroup of a
-    // 4-generation grid (r1: 16 workgroups per CU, records dealt round-robin; measured r2: profiles/r2_scan_variants.log).
-    // Everything else (candidate lists, single records) keeps the static round-robin loop.
+    // Whole-database scans (host-known record count, more records than resident workgroups): workgroups DRAW their records
+    // from per-XCD ticket counters instead of a static round-robin deal, so the work stays balanced to the last record
+    // (measured r2, one stream, L = 10 000 x 64: 168.5 vs 171.0 us, L = 100 000: 1499 vs 1547 us with ONE resident
+    // generation of workgroups).  But one generation that lives as long as the launch starves the other streams of a
+    // multi-context run: their small kernels get no CU until the scan drains (bench.py, 4 streams: 4800 frames/s against
+    // 5050 with r1's static 16-workgroups-per-CU grid, same box).  So a workgroup serves a QUOTA of records and leaves:
+    // the grid holds 6 generations and the deal is still dynamic -- 5110-5200 frames/s in the same runs (2 / 3 / 4 / 6 / 8 /
+    // 12 / 16 generations: 4890 / 4890 / 5030 / 5160 / 5100 / 4960 / 5090; profiles/r2_scan_generations.log).  The price is
+    // the descriptor prologue once per workgroup: the scan alone takes 175 instead of 170 us (RELOC_SCAN_GENS=-1 = one
+    // generation, the fastest form for a single stream).
+    // The short records of the 128-column kernel do not cover the draw latency (Q <= 32: 66 vs 55 us): static there, as
+    // for candidate lists and single records.
     const int resident = ctx->num_cu * 4;          // 4 workgroups of 4 waves per CU (128-VGPR kernel)
     int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
     u32 *ticket = nullptr;
-    // (measured r2, L = 10 000 x 64: Q = 500 168.5 vs 171.0 us, L = 100 000 1499 vs 1547 us; the short records of the
-    // 128-column kernel do not cover the draw latency, Q <= 32: 66 vs 55 us, so those keep the static deal)
+    int quota = 0;
     if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0 && nj == 8) {
         ticket = ctx->scan_ticket;
-        grid = resident;
+        const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 6;
+        quota = (n_ids_max + resident * gens - 1) / (resident * gens);    // records per workgroup
+        grid = (n_ids_max + quota - 1) / quota;                           // grid x quota >= records: every ticket is served
+        if (ctx->scan_gens < 0) { quota = 0; grid = resident; }           // developer switch: one generation, no quota
     }
     if (grid > n_ids_max) grid = n_ids_max;
 #define RELOC_LAUNCH_SCAN(NJ, EMIT)                                                                                          \
     hipLaunchKernelGGL((k_db_scan<NJ, EMIT>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
-                       m_n, emit_stride, mask, ticket)
+                       m_n, emit_stride, mask, ticket, quota)
     if (m_qidx) {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true); else RELOC_LAUNCH_SCAN(8, true);
     } else {

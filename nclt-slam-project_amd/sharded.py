@@ -11,6 +11,10 @@ the anchor.  Both collectives are latency-bound (hundreds of bytes), not xGMI-ba
 A 10k-record database is 20 MB: it fits one MI355X thousands of times over, so sharding buys scan
 throughput, not capacity (bench.py shards frames instead; this module is the path for databases
 that are scanned faster split, BASELINE.json config 4).
+
+Load order: PyTorch-ROCm ships its own HIP runtime.  `import torch` must happen before the first Engine is created
+(before libreloc_hip.so loads /opt/rocm's runtime), otherwise torch reports "No HIP GPUs are available" when it
+initialises later.  bench.py and tests/conftest.py import torch first; do the same in a process that uses this module.
 """
 from __future__ import annotations
 

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:        # torch brings its own HIP runtime: it has to be loaded before libreloc_hip.so pulls in /opt/rocm's, or torch later
+    import torch  # noqa: F401  # reports "No HIP GPUs are available" (only the multi-GPU exchange and bench.py use torch)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
