@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--records", type=int, default=10000)
     ap.add_argument("--rows", default="fixed64", help="fixed64 | ragged | <int>")
     ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1, help="frames per whole-database scan launch on each stream (1..8)")
     ap.add_argument("--size", default="480p", choices=["480p", "720p"])
     ap.add_argument("--shard-db", action="store_true",
                     help="BASELINE config 4 shape: ONE frame stream, the database split by record over the ranks, per frame an\n"
@@ -319,16 +320,21 @@ def main():
     if args.matrix_only:
         return bench_matrix(args, rank, world, local_rank, dist, torch)
 
-    engines = [Engine(local_rank, W, H, 2048) for _ in range(args.streams)]
+    # args.streams streams; on each, args.batch contexts (one per frame of a batch) that share the stream, so that the
+    # whole-database scans of a batch are ONE launch (reloc_tick_batch_dev).  All contexts scan one resident database.
+    S, NB = args.streams, max(1, min(8, args.batch))
+    groups = [[Engine(local_rank, W, H, 2048) for _ in range(NB)] for _ in range(S)]
+    engines = [e for g in groups for e in g]
     n_distinct = 8
     frames, db, base_poses = build_workload(engines[0], args.records, args.rows, n_distinct)
     engines[0].db_upload(*db)
     for e in engines[1:]:
-        e.db_share(engines[0])                         # all streams scan ONE resident copy of the database
+        e.db_share(engines[0])                         # all contexts scan ONE resident copy of the database
     # every ctx enqueues on a torch-made stream so that torch events can time the steps without synchronising
-    tstreams = [torch.cuda.Stream(device=local_rank) for _ in engines]
-    for e, ts in zip(engines, tstreams):
-        e.set_stream(ts.cuda_stream)
+    tstreams = [torch.cuda.Stream(device=local_rank) for _ in range(S)]
+    for g, ts in zip(groups, tstreams):
+        for e in g:
+            e.set_stream(ts.cuda_stream)
     e0 = engines[0]
     frames_dev = [e0.to_device(f) for f in frames]                       # resident frames (judged mode)
     frames_pin = []
@@ -336,22 +342,28 @@ def main():
         p = e0.pinned(f.shape, np.uint8)
         p[...] = f
         frames_pin.append(p)
-    stage = [e.dev_alloc(W * H * 3) for e in engines]                     # per-stream upload target
-    B = args.frames_per_step
+    stage = {id(e): e.dev_alloc(W * H * 3) for e in engines}              # per-context upload target
+    B = args.frames_per_step // NB * NB
     results = e0.pinned((B, 96), np.uint8)                                # one result record per frame of a step
-    res_dev = [e.tick_result_dev for e in engines]
+    res_dev = {id(e): e.tick_result_dev for e in engines}
 
     def step(seed0, ingest):
-        for i in range(B):
-            s = i % len(engines)
-            f = i % n_distinct
-            e = engines[s]
+        for c in range(B // NB):                                          # one batch of NB frames per call
+            g = groups[c % S]
+            fs = [(c * NB + j) % n_distinct for j in range(NB)]
             if ingest:
-                e.h2d_async(stage[s], frames_pin[f])                      # 921.6 KB over PCIe, same stream as its tick
-                e.tick_dev(stage[s], W, H, base_poses[f], order_rgb=False, global_reloc=True, seed=seed0 + i)
+                for j, e in enumerate(g):
+                    e.h2d_async(stage[id(e)], frames_pin[fs[j]])          # 921.6 KB over PCIe, same stream as its tick
+                imgs = [stage[id(e)] for e in g]
             else:
-                e.tick_dev(frames_dev[f], W, H, base_poses[f], order_rgb=False, global_reloc=True, seed=seed0 + i)
-            e.d2h_async(results[i], res_dev[s])                           # every frame's result goes back to the host
+                imgs = [frames_dev[f] for f in fs]
+            if NB == 1:
+                g[0].tick_dev(imgs[0], W, H, base_poses[fs[0]], order_rgb=False, global_reloc=True, seed=seed0 + c)
+            else:
+                Engine.tick_batch_dev(g, imgs, W, H, [base_poses[f] for f in fs], global_reloc=True,
+                                      seeds=[seed0 + c * NB + j for j in range(NB)])
+            for j, e in enumerate(g):
+                e.d2h_async(results[c * NB + j], res_dev[id(e)])          # every frame's result goes back to the host
 
     def sync_all():
         for e in engines:
@@ -367,7 +379,7 @@ def main():
         sync_all()
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(tstreams[0])
-        marks = [[torch.cuda.Event(enable_timing=True) for _ in engines] for _ in range(args.steps)]
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in tstreams] for _ in range(args.steps)]
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k * B, ingest)
@@ -406,7 +418,12 @@ def main():
         e.profile_enable(True)
         n_prof = 40
         for i in range(n_prof):
-            e.tick_dev(frames_dev[i % n_distinct], W, H, base_poses[i % n_distinct], False, True, i)
+            if NB == 1:
+                e.tick_dev(frames_dev[i % n_distinct], W, H, base_poses[i % n_distinct], False, True, i)
+            else:      # the launch the timed region ran: one scan for NB frames
+                fs = [(i * NB + j) % n_distinct for j in range(NB)]
+                Engine.tick_batch_dev(groups[0], [frames_dev[f] for f in fs], W, H, [base_poses[f] for f in fs], global_reloc=True,
+                                      seeds=[i * NB + j for j in range(NB)])
         e.sync()
         scan_ms, scan_n = e.profile_get(0)
         orb_ms, orb_n = e.profile_get(2)
@@ -419,22 +436,22 @@ def main():
             for i in range(120):
                 t0 = time.perf_counter()
                 e.tick_dev(frames_dev[i % n_distinct], W, H, base_poses[i % n_distinct], False, mode, i)
-                e.d2h_async(results[0], res_dev[0])
+                e.d2h_async(results[0], res_dev[id(e)])
                 e.sync()
                 ts_.append(time.perf_counter() - t0)
             ts_ = np.array(ts_[20:]) * 1e6
             lat[name + "_us"] = dict(median=float(np.median(ts_)), p95=float(np.percentile(ts_, 95)))
         desc, pts, off, poses = db
         T, L, Q = int(off[-1]), len(off) - 1, 500
-        alg_bytes = 32 * T + 32 * Q + 4 * L               # database once, queries once, one count per record
+        alg_bytes = NB * (32 * T + 32 * Q + 4 * L)        # per frame: database once, queries once, one count per record; NB frames per launch
         scan_s = scan_ms / max(scan_n, 1) * 1e-3
-        pairs = T * Q
+        pairs = NB * T * Q
         # VALU ceilings measured on MI355X (tools/ubench_valu2.hip, profiles/r2_ubench_valu2.log): the bare distance,
         # 8 x (v_xor_b32 s,v ; accumulating v_bcnt_u32_b32), reaches 2.99 T pairs/s at 8 waves/SIMD (2.91 T at the
         # kernel's 4); with the kernel's argmin bookkeeping in the stream (shl16 + or + 3 min16 per pair) 2.21 T at 4
         valu_peak_pairs = 2.99e12
-        roofline = dict(kernel="k_db_scan", bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
-                        frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=pmc_traffic("k_db_scan"),
+        roofline = dict(kernel="k_db_scan" if NB == 1 else "k_db_scan_batch", frames_per_launch=NB, bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
+                        frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=(pmc_traffic("k_db_scan") or 0) * NB or None,
                         avg_launch_us=scan_s * 1e6, launches=scan_n, algorithmic_bytes=alg_bytes,
                         note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %",
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
@@ -444,7 +461,7 @@ def main():
                                   basis="measured chip ceiling of the bare 256-bit distance, 8 v_xor_b32 (full rate) + 8 accumulating "
                                         "v_bcnt_u32_b32 (half rate) per pair (tools/ubench_valu2.hip); spec issue = 256 CU x 4 SIMD-32 x "
                                         "2.4 GHz counts every instruction at full rate"))
-        stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan=scan_s * 1e6, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
+        stage_us = dict(orb=orb_ms / max(orb_n, 1) * 1e3, db_scan_per_frame=scan_s * 1e6 / NB, pnp=pnp_ms / max(pnp_n, 1) * 1e3)
         roofline_matrix = None
         if not args.no_matrix:
             F = K = 20000
@@ -480,7 +497,7 @@ def main():
             "config": {"workload": f"{W}x{H} BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
                                    f"top-25 PnP-RANSAC(200); frames resident in HBM, every frame's result copied to the host",
-                       "frames_per_step": B, "streams": args.streams, "records": L, "descriptors": T,
+                       "frames_per_step": B, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
                        "parallelism": "frames sharded across ranks, database replicated, no collective"},
             "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95))),
             "host_ingest": ingest, "latency": lat,

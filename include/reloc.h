@@ -240,6 +240,12 @@ int reloc_tick(reloc_ctx *ctx, const uint8_t *img, int w, int h, int order, cons
  * result in a ctx-owned device record readable with reloc_tick_result(). */
 int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order,
                    const double base_pose[7], int global_reloc, uint64_t seed);
+/* Batched relocalization (BASELINE.json config 4): n <= 8 frames, one context per frame; the contexts share ONE stream
+ * (reloc_set_stream), one device and one database (reloc_db_share).  ORB of every frame, then ONE launch that scans the
+ * database for all n frames (the launch-fixed cost of the scan is paid once per batch), then ranking / matches / PnP /
+ * gates per frame.  Results per context as after reloc_tick_dev.  base_poses: n x 7, seeds: n or NULL. */
+int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
+                         const double *base_poses, int global_reloc, const uint64_t *seeds);
 int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
                       int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
 /* Device address of the 96-byte result record of the last tick (layout of reloc_tick_result_ex's outputs: double

@@ -74,6 +74,7 @@ SIGNATURES = {
     "reloc_tick_accumulate_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, P, C.c_int]),
     "reloc_accumulate_result": (C.c_int, [c_ctx, P, P, P]),
     "reloc_tick_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64]),
+    "reloc_tick_batch_dev": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]),
     "reloc_tick_result": (C.c_int, [c_ctx, P, P, P, P, P, P]),
     "reloc_tick_scan_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, P, P, C.c_int]),
     "reloc_tick_solve_dev": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, u64]),

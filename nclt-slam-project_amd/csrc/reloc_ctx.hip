@@ -78,8 +78,8 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->tick_res, 1);
     rc |= dalloc(&c->accum_res, 1);
     rc |= dalloc(&c->tick_flags, 4);
-    rc |= dalloc(&c->scan_ticket, 9 * 32);
-    if (rc == 0 && hipMemset(c->scan_ticket, 0, 9 * 32 * 4) != hipSuccess) rc = RELOC_E_HIP;
+    rc |= dalloc(&c->scan_ticket, (8 * 8 + 1) * 32);
+    if (rc == 0 && hipMemset(c->scan_ticket, 0, (8 * 8 + 1) * 32 * 4) != hipSuccess) rc = RELOC_E_HIP;
     return rc;
 }
 

@@ -243,7 +243,7 @@ struct reloc_ctx {
     int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
-    uint32_t *scan_ticket = nullptr; // 8 per-XCD record counters + 1 exit counter, 128 bytes apart (k_db_scan ticket scheduling)
+    uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 
     // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----
     DbArena db_slot[2];
@@ -287,6 +287,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
                    int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask = nullptr);
+int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double cos_tol, bool auto_mode);
 int db_reindex(reloc_ctx *ctx);
 int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows);
 inline bool db_ready(const reloc_ctx *ctx) { return ctx->db_desc && ctx->db_off && ctx->db_pose && ctx->db_xy_heading && ctx->db_counts && ctx->db_records > 0; }

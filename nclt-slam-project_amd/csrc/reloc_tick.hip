@@ -477,6 +477,39 @@ RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double 
     return db_reindex(ctx);
 }
 
+// The tick in three parts, so that several contexts on one stream can share ONE scan launch (reloc_tick_batch_dev):
+//   begin: ORB, local candidates;  scan: whole-database scan (single or batched);  end: ranking, matches, PnP, gates.
+static int tick_begin(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const TickParams &prm)
+{
+    int rc;
+    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
+    if (prm.mode != RELOC_TICK_GLOBAL) launch_candidates_local(ctx, prm);
+    return RELOC_OK;
+}
+
+static int tick_scan_single(reloc_ctx *ctx, const TickParams &prm)
+{
+    // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others).  In AUTO
+    // mode the scan and the ranking stand down on the device when the local search has found candidates.
+    ScanMask mask;
+    mask.xyh = ctx->db_xy_heading;
+    for (int k = 0; k < 4; ++k) mask.q[k] = prm.base_pose[3 + k];
+    mask.cos_tol = prm.cos_tol;
+    mask.skip_if = prm.mode == RELOC_TICK_AUTO ? ctx->cand_n : nullptr;
+    reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
+    const int rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
+                                  ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
+                                  &mask);
+    reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
+    return rc;
+}
+
+static int tick_end(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
+{
+    if (prm.mode != RELOC_TICK_LOCAL) launch_topk_counts(ctx, ctx->prm.global_max_candidates, ctx->cand_ids, nullptr, prm.mode == RELOC_TICK_AUTO);
+    return tick_solve(ctx, prm, seed);
+}
+
 RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                              int global_reloc, uint64_t seed)
 {
@@ -484,27 +517,47 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (ctx->max_feat > 65535) { reloc_set_error("tick: max_feat must be <= 65535"); return RELOC_E_CAPACITY; }
     int rc;
-    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
-    const int mode = global_reloc;
-    const TickParams prm = make_tick_params(ctx, base_pose, mode, -1);
-    if (mode != RELOC_TICK_GLOBAL) launch_candidates_local(ctx, prm);
-    if (mode != RELOC_TICK_LOCAL) {
-        // G:329-344: only heading-compatible records are scored (the scan leaves count 0 on the others).  In AUTO
-        // mode the scan and the ranking stand down on the device when the local search has found candidates.
-        ScanMask mask;
-        mask.xyh = ctx->db_xy_heading;
-        for (int k = 0; k < 4; ++k) mask.q[k] = base_pose[3 + k];
-        mask.cos_tol = prm.cos_tol;
-        mask.skip_if = mode == RELOC_TICK_AUTO ? ctx->cand_n : nullptr;
-        reloc_prof_begin(ctx, RELOC_PROF_DB_SCAN);
-        rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, nullptr, nullptr, (int)ctx->db_records, ctx->f_desc,
-                            ctx->f_count, ctx->max_feat, ctx->db_max_rows, ctx->db_counts, nullptr, nullptr, nullptr, nullptr, 0,
-                            &mask);
-        reloc_prof_end(ctx, RELOC_PROF_DB_SCAN);
-        if (rc) return rc;
-        launch_topk_counts(ctx, ctx->prm.global_max_candidates, ctx->cand_ids, nullptr, mode == RELOC_TICK_AUTO);
+    const TickParams prm = make_tick_params(ctx, base_pose, global_reloc, -1);
+    if ((rc = tick_begin(ctx, img_dev, w, h, order, prm))) return rc;
+    if (prm.mode != RELOC_TICK_LOCAL && (rc = tick_scan_single(ctx, prm))) return rc;
+    return tick_end(ctx, prm, seed);
+}
+
+RELOC_API int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
+                                   const double *base_poses, int global_reloc, const uint64_t *seeds)
+{
+    ARG_CHECK(ctxs && imgs_dev && base_poses && n >= 1 && n <= 8 && w >= 64 && h >= 64 && global_reloc >= 0 && global_reloc <= 2,
+              "reloc_tick_batch_dev");
+    for (int f = 0; f < n; ++f) {
+        reloc_ctx *c = ctxs[f];
+        ARG_CHECK(c && imgs_dev[f], "reloc_tick_batch_dev: NULL context or frame");
+        if (!db_ready(c)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+        if (c->stream != ctxs[0]->stream || c->device != ctxs[0]->device || c->db_desc != ctxs[0]->db_desc ||
+            c->db_records != ctxs[0]->db_records || c->max_feat != ctxs[0]->max_feat) {
+            reloc_set_error("tick batch: the contexts must share one stream (reloc_set_stream), one device and one database "
+                            "(reloc_db_share) and have equal feature capacity");
+            return RELOC_E_STATE;
+        }
+        for (int g = 0; g < f; ++g) ARG_CHECK(ctxs[g] != c, "reloc_tick_batch_dev: a context appears twice");
     }
-    return tick_solve(ctx, prm, seed);
+    (void)hipSetDevice(ctxs[0]->device);
+    int rc;
+    TickParams prm[8];
+    double q[8 * 4];
+    for (int f = 0; f < n; ++f) {
+        prm[f] = make_tick_params(ctxs[f], base_poses + 7 * f, global_reloc, -1);
+        for (int k = 0; k < 4; ++k) q[4 * f + k] = base_poses[7 * f + 3 + k];
+        if ((rc = tick_begin(ctxs[f], imgs_dev[f], w, h, order, prm[f]))) return rc;
+    }
+    if (global_reloc != RELOC_TICK_LOCAL) {
+        reloc_prof_begin(ctxs[0], RELOC_PROF_DB_SCAN);
+        rc = launch_db_scan_batch(ctxs, n, q, prm[0].cos_tol, global_reloc == RELOC_TICK_AUTO);
+        reloc_prof_end(ctxs[0], RELOC_PROF_DB_SCAN);
+        if (rc) return rc;
+    }
+    for (int f = 0; f < n; ++f)
+        if ((rc = tick_end(ctxs[f], prm[f], seeds ? seeds[f] : 0))) return rc;
+    return RELOC_OK;
 }
 
 RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj, int32_t *lm_idx,

@@ -382,6 +382,19 @@ class Engine:
         N.check(self._lib.reloc_tick_dev(self._ctx, C.c_void_p(img_dev), w, h, int(order_rgb), N.ptr(bp),
                                          int(global_reloc), int(seed)), "reloc_tick_dev")
 
+    @staticmethod
+    def tick_batch_dev(engines, imgs_dev, w: int, h: int, base_poses, order_rgb=False, global_reloc=True, seeds=None):
+        """n <= 8 frames through ONE whole-database scan launch: engines[i] processes imgs_dev[i]; the engines share a
+        stream (set_stream) and a database (db_share).  Enqueue only; read engines[i].tick_result() afterwards."""
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e._ctx for e in engines])
+        imgs = (C.c_void_p * n)(*[int(p) for p in imgs_dev])
+        bp = np.ascontiguousarray(base_poses, np.float64).reshape(n, 7)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64).reshape(n)
+        lib = engines[0]._lib
+        N.check(lib.reloc_tick_batch_dev(ctxs, n, imgs, w, h, int(order_rgb), N.ptr(bp), int(global_reloc), N.ptr(sd)),
+                "reloc_tick_batch_dev")
+
     def tick_scan_enqueue(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
         """ORB + whole-shard scan + local top-k, enqueued on the ctx stream; read with tick_scan_fetch(k)."""
         if not hasattr(self, "_topk_dev"):
