@@ -46,6 +46,7 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->blur, pyr);
     rc |= dalloc(&c->nms, pyr);
     rc |= dalloc(&c->rz_tab, (int64_t)NLEV * 2 * 2 * (c->max_w > c->max_h ? c->max_w : c->max_h));
+    rc |= dalloc((char **)&c->pyr_tiles, (int64_t)((c->max_w + 15) / 16) * ((c->max_h + 15) / 16) * 128);   // >= any k_pyramid tiling
     rc |= dalloc(&c->hist, NLEV * 256);
     rc |= dalloc(&c->cand_cnt, NLEV);
     rc |= dalloc(&c->cand_key, (int64_t)NLEV * RELOC_ORB_STAGE1_CAP);
@@ -150,7 +151,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
         c->db_desc = nullptr; c->db_pts3d = nullptr; c->db_kp2d = nullptr; c->db_off = nullptr; c->db_pose = nullptr;
         c->db_xy_heading = nullptr;
     }
-    void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
+    void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->pyr_tiles, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
                     c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
                     c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off,
                     c->db_pose, c->db_xy_heading, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,

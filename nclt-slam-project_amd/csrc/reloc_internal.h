@@ -216,6 +216,8 @@ struct reloc_ctx {
     uint8_t *blur = nullptr;       // blurred levels
     uint8_t *nms = nullptr;        // NMS-kept FAST score maps (stage-1 source, parity tap)
     int32_t *rz_tab = nullptr;     // resize tables (device)
+    void *pyr_tiles = nullptr;     // PyrTile per workgroup of k_pyramid (device)
+    int pyr_ntiles = 0, pyr_lds[NLEV + 1] = {}, pyr_lds_bytes = 0;   // LDS offsets of the level buffers, then the tables
     int32_t *hist = nullptr;       // NLEV x 256 score histograms
     int32_t *cand_cnt = nullptr;   // NLEV counters (stage-1 list sizes)
     uint32_t *cand_key = nullptr;  // NLEV x STAGE1_CAP packed (y<<16|x)

@@ -84,6 +84,31 @@ __device__ __forceinline__ void ham8x2(const u32 q0[8], const u32 q1[8], const u
     d1 = acc1;
 }
 
+// NC 256-bit distances of one row (8 wave-uniform words w, SGPRs) against NC descriptors held in registers, as NC
+// accumulator chains visited round-robin, word by word: xor, its v_bcnt, next column.  The order is pinned with
+// asm volatile because it is the whole point -- measured on MI355X (tools/exp_matrix2.hip, 20000 x 20000, same run):
+//   2 chains interleaved (accumulator reused after 4 instructions)      190 us  2.10 T pairs/s   (compiler-scheduled: same)
+//   4 chains                                                          187 us
+//   8 chains, xor directly followed by its own v_bcnt                   160 us  2.49 T pairs/s
+//   8 chains, xor issued one step ahead of its v_bcnt                   189 us
+//   16 chains                                                           same as 8
+// i.e. a v_bcnt must not read the accumulator a v_bcnt wrote fewer than ~16 instructions earlier, while the xor -> bcnt
+// pair itself wants to stay adjacent.  The compiler's scheduler, left free with the same 8 accumulators, produces 187 us.
+template <int NC>
+__device__ __forceinline__ void ham8_cols(const u32 (&q)[NC][8], const u32 (&w)[8], u32 (&h)[NC])
+{
+#pragma unroll
+    for (int j = 0; j < NC; ++j) h[j] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            u32 x;
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(w[k]), "v"(q[j][k]));
+            asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h[j]) : "v"(x));
+        }
+}
+
 // ---- scalar-cache row prefetch ------------------------------------------------------------------
 // A teach row (32 B, wave-uniform address) arrives through the scalar cache.  Left alone, the compiler
 // places each scalar load directly in front of its first use, which stalls the wave for the whole
@@ -176,7 +201,10 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     auto bitrev = [](int i) { int r = 0; for (int b = 0; b < LOG_R; ++b) r |= ((i >> b) & 1) << (LOG_R - 1 - b); return r; };
     auto row_of = [&](int i) { const int t = bitrev(i); return CLAMP ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
     uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
-    // compile-time row and column indices: the key constants are immediates
+    // compile-time row and column indices: the key constants are immediates.
+    // (Measured and dropped: row i-1's bookkeeping software-pipelined INTO row i's distance chains, one 16-bit instruction
+    // in every second xor/bcnt slot, all pinned with asm volatile -- 164.9 vs 163.7 us at 10 000 records, 1410 vs 1368 us at
+    // 100 000: full-rate instructions are not free between half-rate v_bcnt, the wave's issue slots are what is spent.)
     static_for<R>([&](auto ic_) {
         constexpr int i = decltype(ic_)::value;
         constexpr int t = [](int v) { int r = 0; for (int bb = 0; bb < LOG_R; ++bb) r |= ((v >> bb) & 1) << (LOG_R - 1 - bb); return r; }(i);
@@ -185,19 +213,19 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         if (i + 1 < R) { na = rec[2 * row_of(i + 1)]; nb = rec[2 * row_of(i + 1) + 1]; }   // ... the next one on its way
         __builtin_amdgcn_sched_barrier(0);
         u32 best = 0;
+        {
+            const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            u32 h[NJ];
+            ham8_cols<NJ>(q, w, h);                                    // NJ accumulator chains, order pinned
 #pragma unroll
-        for (int j = 0; j < NJ; j += 2) {
-            u32 h0, h1;
-            ham8x2(q[j], q[j + 1], a, b, 0, 0, h0, h1);
-            const u32 k0 = shl7_u16(h0) | (u32)(t * 8 + j), k1 = shl7_u16(h1) | (u32)(t * 8 + j + 1);
-            cb16[j] = min_u16(cb16[j], k0);                            // best row of column j
-            cb16[j + 1] = min_u16(cb16[j + 1], k1);
-            best = j == 0 ? min_u16(k0, k1) : min_u16(best, min_u16(k0, k1));   // best column of this row
+            for (int j = 0; j < NJ; j += 2) {
+                const u32 k0 = shl7_u16(h[j]) | (u32)(t * 8 + j), k1 = shl7_u16(h[j + 1]) | (u32)(t * 8 + j + 1);
+                cb16[j] = min_u16(cb16[j], k0);                        // best row of column j
+                cb16[j + 1] = min_u16(cb16[j + 1], k1);
+                best = j == 0 ? min_u16(k0, k1) : min_u16(best, min_u16(k0, k1));   // best column of this row
+            }
         }
-        // 32-bit cross-lane key: best << 9 | lane = distance << 16 | t << 12 | slot << 9 | lane.  The row bits
-        // are equal across the lanes of one row, and (slot, lane) orders like the column slot * 64 + lane
         u32 v = (best << 9) | (u32)lane;
-        // binary-counter merge: level l holds the butterfly node over 2^l visited rows; K halves from R/2 down to 1
         if constexpr ((i & 1) == 0) stk[0] = v;
         else {
             v = bfly<R / 2>(stk[0], v, lane);
@@ -860,17 +888,11 @@ __device__ __forceinline__ void matrix_body(const uint4 *__restrict__ A, int64_t
             const uint4 na_ = A[2 * (int64_t)inext], nb_ = A[2 * (int64_t)inext + 1];
             __builtin_amdgcn_sched_barrier(0);
             const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            u32 o[8];
+            ham8_cols<8>(b, rw, o);                                       // 8 accumulator chains, order pinned (see ham8_cols)
             u32 w[4];
 #pragma unroll
-            for (int p = 0; p < 4; p += 2) {                              // two packed registers = two chains interleaved
-                u32 o0 = 0, o1 = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p + 1][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 3][q] ^ rw[q], o1); }
-                o0 <<= 16; o1 <<= 16;                                     // odd column's distance in the high half seeds the even column's chain
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { o0 = bcnt_acc(b[2 * p][q] ^ rw[q], o0); o1 = bcnt_acc(b[2 * p + 2][q] ^ rw[q], o1); }
-                w[p] = o0; w[p + 1] = o1;
-            }
+            for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
             if (whole || i0 + e < n_rows) {
                 char *row = reinterpret_cast<char *>(out + (int64_t)(i0 + e) * nb);            // scalar registers
                 if (FULL || j0 + 8 <= nb) {
@@ -933,7 +955,7 @@ static int launch_matrix(reloc_ctx *ctx, const uint8_t *a, int64_t na, const uin
             }
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k_hamming_matrix, 256, 0) == hipSuccess && api > 0 && api < per_cu)
                 per_cu = api;
-            if (per_cu > 5) per_cu = 5;           // measured: 4 / 5 / 6 resident workgroups per CU 204 / 199 / 200 us
+            if (per_cu > 6) per_cu = 6;           // measured (8 chains): 5 / 6 / 7 resident workgroups per CU 174 / 168 / 189 us
             if (per_cu < 1) per_cu = 1;
         }
         int grid = ctx->num_cu * per_cu;

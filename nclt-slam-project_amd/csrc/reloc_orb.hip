@@ -10,8 +10,9 @@
 // (ctx->nms) use the same geometry, so a level is addressed by one offset in all three.
 //
 // Launches per frame (all on the ctx stream):
-//   k_gray_l0 (or a 2-D copy)            3 B/px in, 1 B/px out, 4 px per lane (dword stores)
-//   k_resize  x7                         level l from level l-1, fixed-point INTER_LINEAR_EXACT
+//   k_pyramid                            gray conversion (or a gray plane) and all 8 levels in one launch: a tile
+//                                        owns a rectangle of every level and derives level l from level l-1 in LDS
+//                                        (fixed-point INTER_LINEAR_EXACT), 4 px per lane, dword stores
 //   k_fast_blur                          one launch, two kinds of tiles over all levels:
 //                                        FAST 32x32 tiles + halo in LDS: segment test, scores of the compacted
 //                                        corners, 3x3 NMS, per-level score histogram (LDS atomics, then global);
@@ -66,49 +67,6 @@ __device__ __forceinline__ int reflect101(int p, int n)
 }
 
 // ---- gray ---------------------------------------------------------------------------------------
-// 4 pixels per lane: 12 source bytes (three aligned dwords when the frame allows it) -> one dword of
-// level 0.  Block 0 also clears the per-frame counters (histograms, candidate counts).
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void k_gray_l0(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
-                                                 uint8_t *__restrict__ dst, int dstride, int32_t *__restrict__ hist,
-                                                 int32_t *__restrict__ cand_cnt)
-{
-    if (blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < NLEV * 256; i += 256) hist[i] = 0;
-        if (threadIdx.x < NLEV) cand_cnt[threadIdx.x] = 0;
-    }
-    const int qpr = (w + 3) >> 2;                       // quads per row
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= qpr * h) return;
-    const int y = q / qpr, x4 = (q - y * qpr) * 4;
-    const uint8_t *s = src + (size_t)y * sstride + 3 * x4;
-    uint8_t px[12];
-    if (ALIGNED) {
-        const u32 *s4 = reinterpret_cast<const u32 *>(s);
-        const u32 d0 = s4[0], d1 = s4[1], d2 = s4[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { px[k] = (d0 >> (8 * k)) & 0xFF; px[4 + k] = (d1 >> (8 * k)) & 0xFF; px[8 + k] = (d2 >> (8 * k)) & 0xFF; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) px[k] = (x4 + k / 3 < w) ? s[k] : 0;
-    }
-    u32 out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c0 = px[3 * k], c1 = px[3 * k + 1], c2 = px[3 * k + 2];
-        const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
-        const int g = (b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
-        if (x4 + k < w) out |= (u32)g << (8 * k);
-    }
-    *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;
-}
-
-__global__ __launch_bounds__(256) void k_clear_counters(int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
-{
-    for (int i = threadIdx.x; i < NLEV * 256; i += 256) hist[i] = 0;
-    if (threadIdx.x < NLEV) cand_cnt[threadIdx.x] = 0;
-}
-
 // plain gray output for reloc_gray_u8 (dense rows)
 __global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
                                                     uint8_t *__restrict__ dst)
@@ -121,54 +79,216 @@ __global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ 
     dst[(size_t)y * w + x] = (uint8_t)((b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT);
 }
 
-// ---- pyramid ------------------------------------------------------------------------------------
-// 4 output pixels per lane.  With a 1.2 scale step their taps span at most 7 source bytes per row, so
-// each source row is fetched as three aligned dwords instead of eight byte loads.  (Rows are padded to
-// a 64-byte stride inside an arena with slack, so the 12-byte window never leaves the allocation.)
-__device__ __forceinline__ u32 byte_at(u32 d0, u32 d1, u32 d2, int k)
+// ---- fused pyramid ------------------------------------------------------------------------------
+// One launch builds level 0 (gray conversion or a copy of a gray plane) AND levels 1..7.  Level l is a
+// resize of level l-1; as seven launches (round 1) that was a dependent chain of tiny kernels, 4.3 us
+// each, 30 us of a 75 us front end.  Here a workgroup owns one rectangle of EVERY level (`o`, 4-pixel
+// aligned in x so it is stored as dwords) and computes, in LDS, the slightly larger rectangle `n` of
+// each level that its rectangles of the levels above need as bilinear taps -- at most one extra
+// row/column per level, so about 2x recomputation at level 0 and less above.  Per pixel the arithmetic
+// is that of a plain per-level resize (same tables, same order), so the planes are bit-identical.  The rectangles and the
+// table slices are worked out by the host once per frame size (orb_prepare).
+#ifndef PYR_TW
+#define PYR_TW 64
+#define PYR_TH 32
+#endif
+constexpr int PT_W = PYR_TW, PT_H = PYR_TH;     // level-0 footprint of a tile
+struct PyrTile {
+    uint16_t o[NLEV][4];    // stored rectangle x0, x1, y0, y1 (x0 multiple of 4; x1 may reach into the row padding)
+    uint16_t n[NLEV][4];    // computed rectangle (x0 multiple of 4, x1 <= level width)
+};
+static_assert(sizeof(PyrTile) == 128, "PyrTile is read as 8 dwordx4");
+
+struct PyrLds { int lev[NLEV]; int tabs; };    // byte offsets of the level buffers and of the table slices in LDS
+
+// gray value of 4 pixels from 12 interleaved bytes / a gray dword
+template <int CH, bool ALIGNED>
+__device__ __forceinline__ void pyr_fetch(const uint8_t *sp, int x4, int w, u32 (&d)[3])
 {
-    const unsigned long long lo = ((unsigned long long)d1 << 32) | d0, hi = ((unsigned long long)d2 << 32) | d1;
-    return (u32)((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4))) & 0xFF);
+    if (ALIGNED) {
+        const u32 *s4 = reinterpret_cast<const u32 *>(sp);
+        d[0] = s4[0];
+        if (CH == 3) { d[1] = s4[1]; d[2] = s4[2]; }
+    } else {
+        d[0] = d[1] = d[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 4 * CH; ++k)
+            if (x4 + k / CH < w) d[k >> 2] |= (u32)sp[k] << (8 * (k & 3));
+    }
 }
 
-__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src, int sw, int sh, int sstride,
-                                                uint8_t *__restrict__ dst, int dw, int dh, int dstride,
-                                                const int32_t *__restrict__ xofs, const int32_t *__restrict__ xcoef,
-                                                const int32_t *__restrict__ yofs, const int32_t *__restrict__ ycoef)
+template <int CH>
+__device__ __forceinline__ u32 pyr_gray4(const u32 (&d)[3], int x4, int w, int order_rgb)
 {
-    const int qpr = dstride >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= qpr * dh) return;
-    const int y = q / qpr, x4 = (q - y * qpr) * 4;
+    if (CH == 1) return d[0];     // bytes beyond w are 0 (unaligned fetch) or do not exist (aligned: w % 4 == 0)
     u32 out = 0;
-    if (x4 < dw) {
-        const int y0 = yofs[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
-        const u32 b = (u32)ycoef[y];
-        const u32 one = 1u << RELOC_RESIZE_COEF_BITS;
-        int xo[4];
-        u32 xa[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x = x4 + k < dw ? x4 + k : dw - 1;
-            xo[k] = xofs[x];
-            xa[k] = (u32)xcoef[x];
-        }
-        const int base = xo[0] & ~3;
-        const u32 *r0 = reinterpret_cast<const u32 *>(src + (size_t)y0 * sstride + base);
-        const u32 *r1 = reinterpret_cast<const u32 *>(src + (size_t)y1 * sstride + base);
-        const u32 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+    for (int k = 0; k < 4; ++k) {
+        int c[3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (x4 + k < dw) {
-                const int k0 = xo[k] - base, k1 = (xo[k] + 1 < sw ? xo[k] + 1 : sw - 1) - base;
-                const u32 h0 = byte_at(a0, a1, a2, k0) * (one - xa[k]) + byte_at(a0, a1, a2, k1) * xa[k];
-                const u32 h1 = byte_at(b0, b1, b2, k0) * (one - xa[k]) + byte_at(b0, b1, b2, k1) * xa[k];
-                const u32 v = h0 * (one - b) + h1 * b;
-                out |= ((v + (1u << 15)) >> 16) << (8 * k);
-            }
+        for (int j = 0; j < 3; ++j) { const int bi = 3 * k + j; c[j] = (d[bi >> 2] >> (8 * (bi & 3))) & 0xFF; }
+        const int b = order_rgb ? c[2] : c[0], r = order_rgb ? c[0] : c[2];
+        const int g = (b * RELOC_GRAY_CB + c[1] * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
+        if (x4 + k < w) out |= (u32)g << (8 * k);
+    }
+    return out;
+}
+
+// flat table index i -> positions of the (offset, coefficient) entries in the resize tables; the level is found
+// by selects over uniform values so that no load depends on it
+__device__ __forceinline__ void pyr_tab_index(const OrbTable *__restrict__ tab, const PyrTile &T, const int (&tbase)[NLEV + 1], int i,
+                                              int &po, int &pc)
+{
+    int j = i, nw = 0, x0 = 0, y0 = 0, ox = 0, cx = 0, oy = 0, cy = 0;
+#pragma unroll
+    for (int k = 1; k < NLEV; ++k) {
+        const bool m = i >= tbase[k];
+        j = m ? i - tbase[k] : j;
+        nw = m ? T.n[k][1] - T.n[k][0] : nw;
+        x0 = m ? (int)T.n[k][0] : x0;
+        y0 = m ? (int)T.n[k][2] : y0;
+        ox = m ? tab->rz_off[k][0] : ox;
+        cx = m ? tab->rz_off[k][1] : cx;
+        oy = m ? tab->rz_off[k][2] : oy;
+        cy = m ? tab->rz_off[k][3] : cy;
+    }
+    const bool isx = j < nw;
+    const int p = isx ? x0 + j : y0 + j - nw;
+    po = (isx ? ox : oy) + p;
+    pc = (isx ? cx : cy) + p;
+}
+
+// q / d for the small quad counts of a tile (q < 2^16, d <= 2^8): exact through one float multiply
+__device__ __forceinline__ int pyr_div(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }
+
+#ifndef PYR_BS
+#define PYR_BS 256
+#endif
+template <int CH, bool ALIGNED>
+__global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,
+                                                 const int32_t *__restrict__ rz, const uint8_t *__restrict__ src, int w, int h,
+                                                 int sstride, int order_rgb, uint8_t *__restrict__ pyr, PyrLds lds,
+                                                 int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
+{
+    extern __shared__ u32 s_pyr[];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < NLEV * 256; i += PYR_BS) hist[i] = 0;
+        if (tid < NLEV) cand_cnt[tid] = 0;
+    }
+    const PyrTile &T = tiles[blockIdx.x];
+    uint8_t *const base = reinterpret_cast<uint8_t *>(s_pyr);
+    u32 *const tabs = s_pyr + (lds.tabs >> 2);
+    // ---- phase A: every global read of the tile, issued before anything waits ---------------------
+    // table slices of the levels this tile touches, one flat index over (level, x | y): offset | coefficient << 16
+    int tbase[NLEV + 1];
+    tbase[1] = 0;
+#pragma unroll
+    for (int l = 1; l < NLEV; ++l) tbase[l + 1] = tbase[l] + (T.n[l][1] - T.n[l][0]) + (T.n[l][3] - T.n[l][2]);
+    constexpr int TAB_IT = 1024 / PYR_BS, L0_IT = 1536 / PYR_BS;
+    u32 tv[TAB_IT][2];
+#pragma unroll
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = tid + it * PYR_BS;
+        tv[it][0] = tv[it][1] = 0;
+        if (i < tbase[NLEV]) {
+            int po, pc;
+            pyr_tab_index(tab, T, tbase, i, po, pc);
+            tv[it][0] = (u32)rz[po];
+            tv[it][1] = (u32)rz[pc];
         }
     }
-    *reinterpret_cast<u32 *>(dst + (size_t)y * dstride + x4) = out;   // padding columns are written as 0
+    const int x00 = T.n[0][0], y00 = T.n[0][2], qpr0 = (T.n[0][1] - x00 + 3) >> 2, nq0 = qpr0 * (T.n[0][3] - y00);
+    const float inv0 = 1.0f / (float)(qpr0 > 0 ? qpr0 : 1);
+    u32 fv[L0_IT][3];
+#pragma unroll
+    for (int it = 0; it < L0_IT; ++it) {
+        const int q = tid + it * PYR_BS;
+        if (q < nq0) {
+            const int ry = pyr_div(q, inv0), x4 = x00 + (q - ry * qpr0) * 4;
+            pyr_fetch<CH, ALIGNED>(src + (size_t)(y00 + ry) * sstride + CH * x4, x4, w, fv[it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = tid + it * PYR_BS;
+        if (i < tbase[NLEV]) tabs[i] = tv[it][0] | tv[it][1] << 16;
+    }
+#pragma unroll
+    for (int it = 0; it < L0_IT; ++it) {
+        const int q = tid + it * PYR_BS;
+        if (q < nq0) {
+            const int ry = pyr_div(q, inv0), x4 = x00 + (q - ry * qpr0) * 4;
+            reinterpret_cast<u32 *>(base + lds.lev[0])[q] = pyr_gray4<CH>(fv[it], x4, w, order_rgb);      // pitch = 4 * qpr0
+        }
+    }
+    for (int q = tid + L0_IT * PYR_BS; q < nq0; q += PYR_BS) {        // larger tiles than planned for: plain loop
+        const int ry = pyr_div(q, inv0), x4 = x00 + (q - ry * qpr0) * 4;
+        u32 d[3];
+        pyr_fetch<CH, ALIGNED>(src + (size_t)(y00 + ry) * sstride + CH * x4, x4, w, d);
+        reinterpret_cast<u32 *>(base + lds.lev[0])[q] = pyr_gray4<CH>(d, x4, w, order_rgb);
+    }
+    for (int i = tid + TAB_IT * PYR_BS; i < tbase[NLEV]; i += PYR_BS) {
+        int po, pc;
+        pyr_tab_index(tab, T, tbase, i, po, pc);
+        tabs[i] = (u32)rz[po] | (u32)rz[pc] << 16;
+    }
+    __syncthreads();
+    // ---- phase B: levels 1..7 in LDS, each in its own buffer -----------------------------------------
+#pragma unroll
+    for (int l = 0; l + 1 < NLEV; ++l) {
+        const int sw = tab->lev[l].w, sh = tab->lev[l].h;
+        const uint8_t *cur = base + lds.lev[l];
+        u32 *nxt = reinterpret_cast<u32 *>(base + lds.lev[l + 1]);
+        const int nx0 = T.n[l][0], ny0 = T.n[l][2], pitch = ((T.n[l][1] - nx0 + 3) >> 2) << 2;
+        const int dx0 = T.n[l + 1][0], dx1 = T.n[l + 1][1], dh = T.n[l + 1][3] - T.n[l + 1][2];
+        const int qpr = (dx1 - dx0 + 3) >> 2;
+        const u32 *xt = tabs + tbase[l + 1], *yt = xt + (dx1 - dx0);
+        const u32 one = 1u << RELOC_RESIZE_COEF_BITS;
+        const float inv = 1.0f / (float)(qpr > 0 ? qpr : 1);
+        for (int q = tid; q < qpr * dh; q += PYR_BS) {
+            const int ry = pyr_div(q, inv), rx4 = (q - ry * qpr) * 4;
+            const u32 ye = yt[ry];
+            const int sy0 = (int)(ye & 0xFFFF), sy1 = sy0 + 1 < sh ? sy0 + 1 : sh - 1;
+            const u32 b = ye >> 16;
+            const uint8_t *r0 = cur + (sy0 - ny0) * pitch - nx0, *r1 = cur + (sy1 - ny0) * pitch - nx0;
+            u32 out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (dx0 + rx4 + k < dx1) {
+                    const u32 xe = xt[rx4 + k];
+                    const int k0 = (int)(xe & 0xFFFF), k1 = k0 + 1 < sw ? k0 + 1 : sw - 1;
+                    const u32 a = xe >> 16;
+                    const u32 h0 = (u32)r0[k0] * (one - a) + (u32)r0[k1] * a;
+                    const u32 h1 = (u32)r1[k0] * (one - a) + (u32)r1[k1] * a;
+                    const u32 v = h0 * (one - b) + h1 * b;
+                    out |= ((v + (1u << 15)) >> 16) << (8 * k);
+                }
+            }
+            nxt[q] = out;      // pitch = 4 * qpr
+        }
+        __syncthreads();
+    }
+    // ---- phase C: every level's own rectangle to HBM, nothing waits on these stores -------------------
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l) {
+        const OrbLevel L = tab->lev[l];
+        const uint8_t *cur = base + lds.lev[l];
+        const int nx0 = T.n[l][0], ny0 = T.n[l][2], pitch = ((T.n[l][1] - nx0 + 3) >> 2) << 2;
+        const int x0 = T.o[l][0], x1 = T.o[l][1], y0 = T.o[l][2], oh = T.o[l][3] - y0;
+        const int qpr = (x1 - x0) >> 2;
+        uint8_t *dst = pyr + L.off;
+        const float inv = 1.0f / (float)(qpr > 0 ? qpr : 1);
+        for (int q = tid; q < qpr * oh; q += PYR_BS) {
+            const int ry = pyr_div(q, inv), x4 = x0 + (q - ry * qpr) * 4;
+            u32 v = 0;
+            if (x4 < L.w) {
+                v = *reinterpret_cast<const u32 *>(cur + (y0 + ry - ny0) * pitch + (x4 - nx0));
+                if (x4 + 4 > L.w) v &= 0xFFFFFFFFu >> (8 * (x4 + 4 - L.w));
+            }
+            *reinterpret_cast<u32 *>(dst + (size_t)(y0 + ry) * L.stride + x4) = v;
+        }
+    }
 }
 
 // ---- blur ---------------------------------------------------------------------------------------
@@ -736,11 +856,66 @@ int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures)
         resize_axis(S.h, D.h, host + pos, host + pos + D.h);
         pos += 2 * D.h;
     }
+    // fused-pyramid tiles: every tile owns a rectangle of every level (proportional split, x on 4-pixel
+    // boundaries, the last column of tiles takes the row padding of levels >= 1, which is stored as 0)
+    // and computes what the levels above need from it (k_pyramid).
+    const int ntx = (w + PT_W - 1) / PT_W, nty = (h + PT_H - 1) / PT_H;
+    PyrTile *tiles = (PyrTile *)calloc((size_t)ntx * nty, sizeof(PyrTile));
+    int lds_lev[NLEV] = {}, lds_t = 0;
+    for (int t = 0; t < ntx * nty; ++t) {
+        const int tx = t % ntx, ty = t / ntx;
+        PyrTile &T = tiles[t];
+        int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;    // needed rectangle of the level above (empty)
+        int tsum = 0;
+        for (int l = NLEV - 1; l >= 0; --l) {
+            const OrbLevel &L = tab.lev[l];
+            const int quads = (l == 0 ? (L.w + 3) / 4 : L.stride / 4);
+            const int ox0 = 4 * (int)((int64_t)tx * quads / ntx), ox1 = 4 * (int)((int64_t)(tx + 1) * quads / ntx);
+            const int oy0 = (int)((int64_t)ty * L.h / nty), oy1 = (int)((int64_t)(ty + 1) * L.h / nty);
+            T.o[l][0] = (uint16_t)ox0; T.o[l][1] = (uint16_t)ox1; T.o[l][2] = (uint16_t)oy0; T.o[l][3] = (uint16_t)oy1;
+            // computed rectangle = own pixels (inside the image) united with the taps of the level above
+            int cx0 = ox0, cx1 = ox1 < L.w ? ox1 : L.w, cy0 = oy0, cy1 = oy1;
+            const bool stores = ox0 < ox1 && oy0 < oy1;                     // may be row padding only
+            const bool own = cx0 < cx1 && cy0 < cy1, need = nx0 < nx1 && ny0 < ny1;
+            if (need) {
+                const int32_t *xo = host + tab.rz_off[l + 1][0], *yo = host + tab.rz_off[l + 1][2];
+                int sx0 = xo[nx0], sx1 = xo[nx1 - 1] + 2, sy0 = yo[ny0], sy1 = yo[ny1 - 1] + 2;
+                if (sx1 > L.w) sx1 = L.w;
+                if (sy1 > L.h) sy1 = L.h;
+                if (own) {
+                    cx0 = cx0 < sx0 ? cx0 : sx0; cx1 = cx1 > sx1 ? cx1 : sx1;
+                    cy0 = cy0 < sy0 ? cy0 : sy0; cy1 = cy1 > sy1 ? cy1 : sy1;
+                } else {
+                    cx0 = sx0; cx1 = sx1; cy0 = sy0; cy1 = sy1;
+                }
+            } else if (!own) {
+                cx0 = cx1 = cy0 = cy1 = 0;
+            }
+            cx0 &= ~3;
+            T.n[l][0] = (uint16_t)cx0; T.n[l][1] = (uint16_t)cx1; T.n[l][2] = (uint16_t)cy0; T.n[l][3] = (uint16_t)cy1;
+            if (!stores) T.o[l][0] = T.o[l][1] = T.o[l][2] = T.o[l][3] = 0;
+            nx0 = cx0; nx1 = cx1; ny0 = cy0; ny1 = cy1;
+            const int bytes = ((cx1 - cx0 + 3) / 4 * 4) * (cy1 - cy0);
+            lds_lev[l] = bytes > lds_lev[l] ? bytes : lds_lev[l];
+            if (l >= 1) tsum += (cx1 - cx0) + (cy1 - cy0);
+        }
+        lds_t = tsum > lds_t ? tsum : lds_t;
+    }
+    ctx->pyr_ntiles = ntx * nty;
+    {
+        int o = 0;
+        for (int l = 0; l < NLEV; ++l) { ctx->pyr_lds[l] = o; o += (lds_lev[l] + 15) / 16 * 16; }
+        ctx->pyr_lds[NLEV] = o;
+        ctx->pyr_lds_bytes = o + 4 * lds_t;
+    }
+    if (ctx->pyr_lds_bytes > 64 * 1024) { free(host); free(tiles); reloc_set_error("pyramid tile exceeds LDS"); return RELOC_E_CAPACITY; }
+    hipError_t e0 = hipMemcpyAsync(ctx->pyr_tiles, tiles, sizeof(PyrTile) * (size_t)ntx * nty, hipMemcpyHostToDevice, ctx->stream);
     hipError_t e1 = hipMemcpyAsync(ctx->rz_tab, host, sizeof(int32_t) * (size_t)pos, hipMemcpyHostToDevice, ctx->stream);
     hipError_t e2 = hipMemcpyAsync(ctx->orb_const, &tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream);
     hipError_t e3 = hipStreamSynchronize(ctx->stream);
     free(host);
-    HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
+    free(tiles);
+    HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
     memcpy(ctx->lev, tab.lev, sizeof(tab.lev));
     memcpy(ctx->orb_tab_host, &tab, sizeof(tab));
     ctx->orb_w = w; ctx->orb_h = h; ctx->orb_nfeat = nfeatures;
@@ -756,26 +931,14 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
     const OrbTable *tab_d = (const OrbTable *)ctx->orb_const;
     hipStream_t st = ctx->stream;
     reloc_prof_begin(ctx, RELOC_PROF_ORB);
-    const OrbLevel &L0 = tab_h->lev[0];
-    if (channels == 3) {
-        const int quads = ((w + 3) / 4) * h;
+    {
         const bool aligned = (w % 4 == 0) && (stride % 4 == 0) && (((uintptr_t)src_dev) % 4 == 0);
-        if (aligned)
-            hipLaunchKernelGGL(k_gray_l0<true>, dim3((quads + 255) / 256), dim3(256), 0, st, src_dev, w, h, stride, order,
-                               ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
-        else
-            hipLaunchKernelGGL(k_gray_l0<false>, dim3((quads + 255) / 256), dim3(256), 0, st, src_dev, w, h, stride, order,
-                               ctx->pyr + L0.off, L0.stride, ctx->hist, ctx->cand_cnt);
-    } else {
-        hipLaunchKernelGGL(k_clear_counters, dim3(1), dim3(256), 0, st, ctx->hist, ctx->cand_cnt);
-        HIP_TRY(hipMemcpy2DAsync(ctx->pyr + L0.off, L0.stride, src_dev, stride, w, h, hipMemcpyDeviceToDevice, st));
-    }
-    for (int l = 1; l < NLEV; ++l) {
-        const OrbLevel &S = tab_h->lev[l - 1], &D = tab_h->lev[l];
-        hipLaunchKernelGGL(k_resize, dim3(((D.stride / 4) * D.h + 255) / 256), dim3(256), 0, st, ctx->pyr + S.off, S.w, S.h,
-                           S.stride, ctx->pyr + D.off, D.w, D.h, D.stride, ctx->rz_tab + tab_h->rz_off[l][0],
-                           ctx->rz_tab + tab_h->rz_off[l][1], ctx->rz_tab + tab_h->rz_off[l][2],
-                           ctx->rz_tab + tab_h->rz_off[l][3]);
+        auto kern = channels == 3 ? (aligned ? k_pyramid<3, true> : k_pyramid<3, false>) : (aligned ? k_pyramid<1, true> : k_pyramid<1, false>);
+        PyrLds lds;
+        for (int l = 0; l < NLEV; ++l) lds.lev[l] = ctx->pyr_lds[l];
+        lds.tabs = ctx->pyr_lds[NLEV];
+        hipLaunchKernelGGL(kern, dim3(ctx->pyr_ntiles), dim3(PYR_BS), ctx->pyr_lds_bytes, st, tab_d, (const PyrTile *)ctx->pyr_tiles,
+                           ctx->rz_tab, src_dev, w, h, stride, order, ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
     }
     hipLaunchKernelGGL(k_fast_blur, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr,
                        ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV]);

@@ -404,6 +404,16 @@ class Engine:
                                               C.c_void_p(self._topk_dev), C.c_void_p(self._topk_dev + 128), int(k)),
                 "reloc_tick_scan_dev")
 
+    def orb_frame_dev(self, img_dev: int, w: int, h: int, stride: int | None = None, order_rgb=False, nfeatures: int = 500) -> int:
+        """gray + ORB of an interleaved 3-channel frame resident in device memory (reloc_orb_frame_dev); returns the
+        number of keypoints (synchronises).  Descriptors / coordinates stay on the device; frame_debug_plane() reads planes."""
+        N.check(self._lib.reloc_orb_frame_dev(self._ctx, C.c_void_p(img_dev), int(w), int(h), int(stride or 3 * w),
+                                              int(order_rgb), int(nfeatures)), "reloc_orb_frame_dev")
+        nf = np.empty(1, np.int32)
+        N.check(self._lib.reloc_d2h(self._ctx, N.ptr(nf), C.c_void_p(self._lib.reloc_frame_count_dev(self._ctx)), 4), "reloc_d2h")
+        self.sync()
+        return int(nf[0])
+
     def tick_scan_into(self, img_dev: int, w: int, h: int, base_pose, k: int, ids_dev: int, counts_dev: int, nfeat_dev: int,
                        order_rgb=False):
         """ORB + shard scan + local top-k, everything left in caller-owned device memory (k ids, k counts, 1 feature count);

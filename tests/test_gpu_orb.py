@@ -53,6 +53,29 @@ def test_orb_stages_and_features(engine, oracle, seed, w, h):
         assert n >= 450
 
 
+@pytest.mark.parametrize("seed,w,h,pad,order_rgb", [(11, 640, 480, 0, False), (12, 333, 251, 0, True), (13, 642, 481, 5, False),
+                                                    (14, 64, 64, 0, False), (15, 1279, 719, 3, True), (16, 97, 300, 1, False)])
+def test_pyramid_from_interleaved_frame(engine, oracle, seed, w, h, pad, order_rgb):
+    """the fused pyramid kernel fed with a 3-channel frame in device memory (the tick's input): aligned and unaligned
+    widths / strides, tiles that own only row padding, every level against the oracle's gray + resize chain"""
+    img = _frame(seed, w, h, n_shapes=max(40, w * h // 800))
+    stride = 3 * w + pad
+    raw = np.zeros((h, stride), np.uint8)
+    raw[:, :3 * w] = img.reshape(h, 3 * w)
+    dev = engine.dev_alloc(raw.nbytes)
+    try:
+        engine.h2d(dev, raw)
+        n = engine.orb_frame_dev(dev, w, h, stride, order_rgb=order_rgb)
+    finally:
+        engine.dev_free(dev)
+    gray = oracle.gray_u8(img, order_rgb)
+    pyr = oracle.pyramid(gray)
+    for l in range(8):
+        np.testing.assert_array_equal(engine.frame_debug_plane(0, l), pyr[l], err_msg=f"pyramid level {l}")
+    exp = oracle.orb_detect_compute(gray, 500, max_out=engine.max_feat)
+    assert n == min(exp["n"], engine.max_feat)
+
+
 def test_orb_flat_image_has_no_features(engine):
     g = np.full((480, 640), 77, np.uint8)
     r = engine.orb_detect_compute(g, 500)

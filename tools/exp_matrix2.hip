@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 typedef uint32_t u32;
 __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) { u32 r; asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc)); return r; }
@@ -59,6 +60,86 @@ __global__ __launch_bounds__(256, WPS) void k(const uint4 *__restrict__ A, int64
                     const u32 odd = ham8(b[2 * p + 1], ra, rb, 0);
                     w[p] = ham8(b[2 * p], ra, rb, odd << 16);
                 }
+            } else if (IL == 8 || IL == 9) {
+                // ubench-style: 8 accumulators (one per column), q-major, xor immediately followed by its bcnt, order pinned
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        u32 x;
+                        if (IL == 8) {
+                            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(rw[q]), "v"(b[c][q]));
+                            asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c]) : "v"(x));
+                        } else {
+                            x = b[c][q] ^ rw[q];
+                            o[c] = bcnt_acc(x, o[c]);
+                        }
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
+            } else if (IL == 16) {
+                // 16 accumulators: this row and a copy of it with the words rotated (stands in for a second row's SGPRs):
+                // measures whether a longer accumulator reuse distance than 16 instructions helps further
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        u32 x;
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(rw[(q + (c >> 3)) & 7]), "v"(b[c & 7][q]));
+                        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c]) : "v"(x));
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[p] = (o[2 * p] + o[8 + 2 * p]) | ((o[2 * p + 1] + o[8 + 2 * p + 1]) << 16);
+            } else if (IL == 10) {
+                // 8 accumulators, xor of the NEXT column issued before the bcnt of the current one (no adjacent dependency)
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                u32 x, xn;
+                asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(rw[0]), "v"(b[0][0]));
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    const int q = i >> 3, c = i & 7, qn = (i + 1) >> 3, cn = (i + 1) & 7;
+                    if (i + 1 < 64) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(xn) : "s"(rw[qn]), "v"(b[cn][qn]));
+                    asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c]) : "v"(x));
+                    x = xn;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
+            } else if (IL == 11) {
+                // 8 accumulators, column-major inside groups of 4 dwords: c-major over q pairs (acc reuse distance 8)
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2) {
+                        u32 x0, x1;
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x0) : "s"(rw[q]), "v"(b[c][q]));
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x1) : "s"(rw[q]), "v"(b[c + 1][q]));
+                        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c]) : "v"(x0));
+                        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c + 1]) : "v"(x1));
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
+            } else if (IL == 12) {
+                // 8 accumulators pinned, odd columns first into the high half: no final or/shift per pair (4 chains x 2 phases)
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[4] = {0, 0, 0, 0}, o2[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        u32 x;
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(rw[q]), "v"(b[c][q]));
+                        if (c & 1) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o2[c >> 1]) : "v"(x));
+                        else asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(o[c >> 1]) : "v"(x));
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(w[p]) : "v"(o2[p]), "v"(o[p]));
             } else if (IL == 4) {
                 const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                 u32 o[4] = {0, 0, 0, 0};
@@ -146,6 +227,15 @@ int main()
     (void)hipMalloc(&A, F * 32); (void)hipMalloc(&B, K * 32); (void)hipMalloc(&out, F * K * 2 + 4096);
     (void)hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
     std::vector<Variant> vs;
+    if (getenv("EXP_COMPUTE")) {
+        vs.push_back(make<1, 0, 2, 8, 1>("compute-only il2", A, B, out, F, K, 5));
+        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8acc pinned", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 16, 8, 1>("compute-only 16acc pinned (2x work)", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 2, 8, 1>("full nt il2", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8acc pinned", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 8, 4, 1>("full nt 8acc pinned unit4", A, B, out, F, K, 6));
+        vs.push_back(make<0, 2, 8, 8, 1>("full sc1 8acc pinned", A, B, out, F, K, 6));
+    } else {
     vs.push_back(make<0, 0, 1, 8, 1>("full plain serial (r1 kernel)", A, B, out, F, K, 6));
     vs.push_back(make<0, 1, 1, 8, 1>("full nt serial", A, B, out, F, K, 6));
     vs.push_back(make<0, 1, 1, 8, 1>("full nt serial", A, B, out, F, K, 5));
@@ -159,6 +249,7 @@ int main()
     vs.push_back(make<1, 0, 2, 8, 1>("compute-only il2", A, B, out, F, K, 5));
     vs.push_back(make<2, 1, 1, 8, 1>("store-only nt", A, B, out, F, K, 5));
     vs.push_back(make<2, 0, 1, 8, 1>("store-only plain", A, B, out, F, K, 5));
+    }
     for (auto &v : vs) v.once();                               // warm-up
     for (int round = 0; round < 7; ++round)                    // interleaved rounds: drift of the clock hits all variants alike
         for (auto &v : vs) v.t.push_back(v.once());
