@@ -868,9 +868,10 @@ __device__ __forceinline__ void matrix_body(const uint4 *__restrict__ A, int64_t
     // hides behind the current row's ~135 VALU instructions (see srow_landed).
     // Measured r2 (tools/exp_matrix2.hip, interleaved rounds on one MI355X, 20000 x 20000): the r1 form of this loop
     // 218 us; non-temporal stores (the 800 MB output is written once and never read here: nt keeps it from evicting the
-    // B rows' lines and its store stream alone runs 6.3 instead of 5.7 TB/s) 202 us; two distance chains interleaved
-    // and 5 resident workgroups per CU 199 us = 0.50 of 8 TB/s, within 4 % of the same loop without its store (190 us):
-    // the kernel is bound by the VALU's 2.1 T pairs/s on this formulation, not by HBM.
+    // B rows' lines and its store stream alone runs 6.3 instead of 5.7 TB/s) 202 us; the 8 distances of a lane as 8
+    // accumulator chains in pinned order (ham8_cols) and 6 resident workgroups per CU 168 us = 0.60 of 8 TB/s, the same
+    // loop without its store 160 us: the kernel is bound by the VALU's ~2.5 T pairs/s on this formulation, not by HBM.
+    // (After an idle period the chip needs ~40 ms of load before it runs at this rate: bench.py pre-rolls.)
     // row indices are 32-bit (launch_matrix checks na < 2^31): clamps and bound tests stay on the scalar unit
     const int last = (int)na - 1, n_rows = (int)na;
     auto row_at = [&](int i) { return min(i, last); };

@@ -162,7 +162,7 @@ __device__ __forceinline__ void pyr_tab_index(const OrbTable *__restrict__ tab, 
 __device__ __forceinline__ int pyr_div(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }
 
 #ifndef PYR_BS
-#define PYR_BS 256
+#define PYR_BS 512
 #endif
 template <int CH, bool ALIGNED>
 __global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,

@@ -172,7 +172,14 @@ __global__ __launch_bounds__(256, WPS) void k(const uint4 *__restrict__ A, int64
             if (doit) {
                 uint16_t *o = out + (i0 + e) * nb + j0;
                 const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-                if (ST == 0) *reinterpret_cast<uint4 *>(o) = v;
+                if (ST == 3) {
+                    typedef u32 v4u __attribute__((ext_vector_type(4)));
+                    v4u vv = {w[0], w[1], w[2], w[3]};
+                    char *row = reinterpret_cast<char *>(out + (i0 + e) * nb);
+                    const u32 lane_off = (u32)(j0 * 2);
+                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(vv), "s"(row) : "memory");
+                }
+                else if (ST == 0) *reinterpret_cast<uint4 *>(o) = v;
                 else if (ST == 1) {
                     typedef u32 v4u __attribute__((ext_vector_type(4)));
                     v4u vv = {w[0], w[1], w[2], w[3]};
@@ -228,13 +235,10 @@ int main()
     (void)hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
     std::vector<Variant> vs;
     if (getenv("EXP_COMPUTE")) {
-        vs.push_back(make<1, 0, 2, 8, 1>("compute-only il2", A, B, out, F, K, 5));
-        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8acc pinned", A, B, out, F, K, 6));
-        vs.push_back(make<1, 0, 16, 8, 1>("compute-only 16acc pinned (2x work)", A, B, out, F, K, 5));
-        vs.push_back(make<0, 1, 2, 8, 1>("full nt il2", A, B, out, F, K, 5));
         vs.push_back(make<0, 1, 8, 8, 1>("full nt 8acc pinned", A, B, out, F, K, 6));
-        vs.push_back(make<0, 1, 8, 4, 1>("full nt 8acc pinned unit4", A, B, out, F, K, 6));
-        vs.push_back(make<0, 2, 8, 8, 1>("full sc1 8acc pinned", A, B, out, F, K, 6));
+        vs.push_back(make<0, 3, 8, 8, 1>("full nt(sgpr base) 8acc pinned", A, B, out, F, K, 6));
+        vs.push_back(make<0, 3, 8, 8, 1>("full nt(sgpr base) 8acc pinned", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8acc pinned", A, B, out, F, K, 5));
     } else {
     vs.push_back(make<0, 0, 1, 8, 1>("full plain serial (r1 kernel)", A, B, out, F, K, 6));
     vs.push_back(make<0, 1, 1, 8, 1>("full nt serial", A, B, out, F, K, 6));
@@ -251,7 +255,7 @@ int main()
     vs.push_back(make<2, 0, 1, 8, 1>("store-only plain", A, B, out, F, K, 5));
     }
     for (auto &v : vs) v.once();                               // warm-up
-    for (int round = 0; round < 7; ++round)                    // interleaved rounds: drift of the clock hits all variants alike
+    for (int round = 0; round < 15; ++round)                    // interleaved rounds: drift of the clock hits all variants alike
         for (auto &v : vs) v.t.push_back(v.once());
     for (auto &v : vs) {
         std::sort(v.t.begin(), v.t.end());
