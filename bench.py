@@ -213,6 +213,9 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
 
 
 MATRIX_PREROLL = 400      # untimed launches (~70 ms) before the matrix kernel is timed
+PREROLL_STEPS = 20        # untimed steps (~0.2 s) ahead of the W warm-up steps of the frame benchmark: within the first ~100 ms
+                          # after an idle period the chip changes its clock state once, and a step that meets that change takes
+                          # 50 ms instead of 11 (seen in one of two runs with 3 warm-up steps, in none with 30)
 
 
 def bench_matrix(args, rank, world, local_rank, dist, torch):
@@ -379,15 +382,17 @@ def main():
         torch.cuda.synchronize()
 
     def timed(ingest):
-        for w in range(args.warmup):
+        # the event objects are made BEFORE the warm-up: creating 4 x steps events takes ~40 ms, and a GPU left idle that long
+        # between warm-up and the timed region starts the timed region with its clocks down (first step 5x longer)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in tstreams] for _ in range(args.steps)]
+        for w in range(PREROLL_STEPS + args.warmup):                      # pre-roll (clock governor, see PREROLL_STEPS), then W warm-up steps
             step(w * B, ingest)
         sync_all()
         if dist is not None:
             dist.barrier()
         sync_all()
-        ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(tstreams[0])
-        marks = [[torch.cuda.Event(enable_timing=True) for _ in tstreams] for _ in range(args.steps)]
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k * B, ingest)
@@ -505,9 +510,10 @@ def main():
             "config": {"workload": f"{W}x{H} BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
                                    f"top-25 PnP-RANSAC(200); frames resident in HBM, every frame's result copied to the host",
-                       "frames_per_step": B, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
+                       "frames_per_step": B, "preroll_steps": PREROLL_STEPS, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
                        "parallelism": "frames sharded across ranks, database replicated, no collective"},
-            "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95))),
+            "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95)), max=float(per_step.max()),
+                            first=[round(float(x), 2) for x in per_step[:6]]),
             "host_ingest": ingest, "latency": lat,
             "roofline": roofline, "roofline_matrix": roofline_matrix, "cpu_baseline": cpu,
             "stage_us": stage_us, "hamming_match_GBps": roofline["achieved"], **outcomes,
