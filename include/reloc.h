@@ -252,6 +252,11 @@ int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, flo
  * anchor_pose[7], double reproj, int32 n_inl, lm_idx, outcome, n_candidates, n_features, relocating): lets a pipelined
  * host copy results with reloc_d2h into pinned memory without synchronising per frame. */
 const void *reloc_tick_result_dev(reloc_ctx *ctx);
+/* Streaming without a copy: the ticks enqueued after this call ALSO write their 96-byte result record (same layout) to
+ * `pinned_record`, memory from reloc_host_alloc() -- the last kernel of the tick stores it over PCIe itself, so the record
+ * is complete once the ctx stream has passed that tick (event / reloc_sync).  Point it at a different record before each
+ * tick to keep one per frame; NULL stops it.  (reloc_tick_result() reads an internal record of the same kind.) */
+int reloc_tick_result_to(reloc_ctx *ctx, void *pinned_record);
 /* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344). */
 int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
                          int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "reloc_host_free": (C.c_int, [P]),
     "reloc_get_stream": (P, [c_ctx]),
     "reloc_tick_result_dev": (P, [c_ctx]),
+    "reloc_tick_result_to": (C.c_int, [c_ctx, P]),
     "reloc_db_fetch": (C.c_int, [c_ctx, i64, P, P, P, P, P, P]),
     "reloc_tick_result_ex": (C.c_int, [c_ctx, P, P, P, P, P, P, P, P]),
     "reloc_tick_accumulate_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, P, C.c_int]),

@@ -77,6 +77,11 @@ static int ctx_alloc(reloc_ctx *c)
     rc |= dalloc(&c->p_inl, (int64_t)MAX_CAND * MAX_REC_ROWS);
     rc |= dalloc(&c->p_out, MAX_CAND);
     rc |= dalloc(&c->tick_res, 1);
+    if (hipHostMalloc((void **)&c->tick_res_host, sizeof(TickResult), hipHostMallocDefault) != hipSuccess) {
+        reloc_set_error("hipHostMalloc(result record) failed");
+        c->tick_res_host = nullptr;
+        rc |= RELOC_E_HIP;
+    } else memset(c->tick_res_host, 0, sizeof(TickResult));
     rc |= dalloc(&c->accum_res, 1);
     rc |= dalloc(&c->tick_flags, 4);
     rc |= dalloc(&c->scan_ticket, (8 * 8 + 1) * 32);
@@ -135,6 +140,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
     if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
     if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
+    if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
         return nullptr;
@@ -159,6 +165,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
                     c->p_out, c->tick_res, c->accum_res, c->tick_flags, c->scan_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->tick_res_host) (void)hipHostFree(c->tick_res_host);
     {   // the database that is not selected
         const DbArena &a = c->db_slot[1 - c->db_sel];
         void *q[] = {a.desc, a.pts3d, a.kp2d, a.off, a.pose, a.xy_heading, a.counts, a.topk_part};

@@ -275,7 +275,10 @@ struct reloc_ctx {
     int32_t *p_cnt = nullptr;        // MAX_CAND x MAX_HYP
     int32_t *p_inl = nullptr;        // MAX_CAND x MAX_REC_ROWS
     PnpOut *p_out = nullptr;         // MAX_CAND
+    bool local_two_stage = false;    // developer switch RELOC_LOCAL_TWO_STAGE=1: local candidates by k_topk_part + k_candidates_local
     TickResult *tick_res = nullptr;  // 1
+    TickResult *tick_res_host = nullptr;   // the same record in pinned host memory, written by k_tick_finalize
+    TickResult *tick_res_ext = nullptr;    // caller's pinned record for the next ticks (reloc_tick_result_to), or NULL
 };
 
 int reloc_scratch(reloc_ctx *ctx, int slot, int64_t bytes, void **out);

@@ -526,9 +526,10 @@ __device__ int stage1_cut_wave(const int32_t *__restrict__ hist_l, int n_keep, i
 }
 
 // Harris response of one pixel by a whole wave: lanes 0..48 own one pixel of the 7x7 block each.
-__device__ float harris_wave(const uint8_t *p, int step, int lane)
+// harris_terms: the lane's three products (its byte loads); harris_finish: wave sums + the float formula.
+__device__ __forceinline__ void harris_terms(const uint8_t *p, int step, int lane, int &a, int &b, int &c)
 {
-    int a = 0, b = 0, c = 0;
+    a = b = c = 0;
     if (lane < 49) {
         const int dy = lane / 7 - 3, dx = lane % 7 - 3;
         const uint8_t *q = p + dy * step + dx;
@@ -536,6 +537,10 @@ __device__ float harris_wave(const uint8_t *p, int step, int lane)
         const int iy = (q[step] - q[-step]) * 2 + (q[step - 1] - q[-step - 1]) + (q[step + 1] - q[-step + 1]);
         a = ix * ix; b = iy * iy; c = ix * iy;
     }
+}
+
+__device__ __forceinline__ float harris_finish(int a, int b, int c)
+{
     a = wave_sum_i32(a);                  // integer sums: exact in any order
     b = wave_sum_i32(b);
     c = wave_sum_i32(c);
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
                                                 float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
 {
     __shared__ int s_cut;
-    __shared__ int s_n;
+    __shared__ int s_n, s_base;
     __shared__ u32 s_list[HARRIS_CHUNK];
     const int l = find_level(tab->flat_base, blockIdx.x);
     const OrbLevel L = tab->lev[l];
@@ -594,15 +599,48 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
     const int n = s_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *img = pyr + L.off;
-    for (int i = wave; i < n; i += 4) {
-        const u32 key = s_list[i];
-        const float r = harris_wave(img + (size_t)(key >> 16) * L.stride + (key & 0xFFFF), L.stride, lane);
+    // ONE slot reservation per block, its round trip hidden behind the first responses (the per-survivor atomicAdd it
+    // replaces was a second memory round trip in every turn); each wave takes two survivors per turn so that the pixel
+    // loads of the second are in flight while the first is reduced.
+    int base_ret = 0;
+    if (threadIdx.x == 0 && n > 0) base_ret = atomicAdd(&cand_cnt[l], n);
+    auto terms = [&](u32 key, int &a, int &b, int &c) {
+        harris_terms(img + (size_t)(key >> 16) * L.stride + (key & 0xFFFF), L.stride, lane, a, b, c);
+    };
+    int i = wave * 2;
+    const bool first = i < n;                                  // wave-uniform
+    u32 k0 = 0, k1 = 0;
+    int a0 = 0, b0 = 0, c0 = 0, a1 = 0, b1 = 0, c1 = 0;
+    float h0 = 0.f, h1 = 0.f;
+    if (first) {
+        k0 = s_list[i]; k1 = s_list[i + 1 < n ? i + 1 : i];
+        terms(k0, a0, b0, c0);
+        terms(k1, a1, b1, c1);
+    }
+    if (threadIdx.x == 0) s_base = base_ret;
+    if (first) { h0 = harris_finish(a0, b0, c0); h1 = harris_finish(a1, b1, c1); }
+    __syncthreads();
+    const int base = s_base;
+    auto put = [&](int at, u32 key, float r) {
+        const int pos = base + at;
+        if (pos < RELOC_ORB_STAGE1_CAP) {
+            cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = key;
+            cand_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = r;
+        }
+    };
+    if (first && lane == 0) {
+        put(i, k0, h0);
+        if (i + 1 < n) put(i + 1, k1, h1);
+    }
+    for (i += 8; i < n; i += 8) {
+        k0 = s_list[i]; k1 = s_list[i + 1 < n ? i + 1 : i];
+        terms(k0, a0, b0, c0);
+        terms(k1, a1, b1, c1);
+        h0 = harris_finish(a0, b0, c0);
+        h1 = harris_finish(a1, b1, c1);
         if (lane == 0) {
-            const int pos = atomicAdd(&cand_cnt[l], 1);
-            if (pos < RELOC_ORB_STAGE1_CAP) {
-                cand_key[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = key;
-                cand_resp[(size_t)l * RELOC_ORB_STAGE1_CAP + pos] = r;
-            }
+            put(i, k0, h0);
+            if (i + 1 < n) put(i + 1, k1, h1);
         }
     }
 }

@@ -323,9 +323,77 @@ __global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t
     }
 }
 
-// host side of the two stages (one launch when the database is a single slice)
+// Local candidates in ONE launch (databases up to NEAR_MAX_RECORDS).  Only a record within radius_m can become a
+// candidate, and the nearest-15 cut (M:296) is taken in LocalKey order, which is monotone in the distance at 44-bit
+// resolution: so the nearest 15 of ALL records, as far as they can pass the radius test, are the nearest 15 of
+//   E' = { i : trunc44(d_i) <= trunc44(radius_m) }      (a superset of the records inside the radius),
+// and everything behind E' in that order fails the radius test anyway.  The block collects E' in LDS (a handful of
+// records on a teach path), orders it by rank counting and applies the radius / heading filter in that order exactly as
+// k_candidates_local does.  More than NEAR_CAP records in E': the block ranks all L records itself (block_topk), slower
+// but the same answer.  Replaces k_topk_part + k_candidates_local (9.5 + 7.7 us at 10 000 records) by one ~6 us kernel.
+constexpr int NEAR_CAP = 256, NEAR_MAX_RECORDS = 1 << 17;
+__global__ __launch_bounds__(TICK_BLOCK) void k_candidates_near(const double *__restrict__ xyh, TickParams prm,
+                                                                int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n,
+                                                                int32_t *__restrict__ relocating)
+{
+    __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
+    __shared__ unsigned long long s_keys[TOPK_MAX + 1];
+    __shared__ unsigned long long s_near[NEAR_CAP];
+    __shared__ int s_cnt;
+    const int L = prm.n_records, tid = threadIdx.x;
+    const double vx = prm.base_pose[0], vy = prm.base_pose[1];
+    const LocalKey keyfn{xyh, vx, vy};
+    const int k = min(prm.max_candidates * 3, L);
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // LocalKey's distance field is 0xFFFFFFFFFFF - trunc44(d): "trunc44(d) <= trunc44(r)" is "key field >= that of r"
+    const unsigned long long rfield = 0xFFFFFFFFFFFull - ((unsigned long long)__double_as_longlong(prm.radius_m) >> 20);
+    for (int i = tid; i < L; i += TICK_BLOCK) {
+        const unsigned long long key = keyfn(i);
+        if ((key >> 20) >= rfield) {
+            const int at = atomicAdd(&s_cnt, 1);
+            if (at < NEAR_CAP) s_near[at] = key;
+        }
+    }
+    __syncthreads();
+    const int ne = s_cnt;
+    int n;
+    if (ne <= NEAR_CAP) {
+        // keys are unique: the rank of a key is the number of larger ones
+        if (tid < ne) {
+            const unsigned long long mine = s_near[tid];
+            int rank = 0;
+            for (int j = 0; j < ne; ++j) rank += s_near[j] > mine;
+            if (rank < k) s_keys[rank] = mine;
+        }
+        n = min(ne, k);
+        __syncthreads();
+    } else {
+        n = block_topk(0, L, k, keyfn, s_red, s_keys);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double cc, sc;
+        cur_heading(prm, cc, sc);
+        int m = 0;
+        for (int r = 0; r < n && m < prm.max_candidates; ++r) {
+            const int i = 0xFFFFF - (int)(s_keys[r] & 0xFFFFF);
+            const double dx = xyh[4 * i] - vx, dy = xyh[4 * i + 1] - vy;
+            if (sqrt(dx * dx + dy * dy) < prm.radius_m && heading_ok(xyh + 4 * i, cc, sc, prm.cos_tol)) cand_ids[m++] = i;
+        }
+        *cand_n = m;
+        *relocating = 0;
+    }
+}
+
+// host side: one launch (k_candidates_near), or the two stages for very large databases / RELOC_LOCAL_TWO_STAGE=1
 static void launch_candidates_local(reloc_ctx *ctx, const TickParams &prm)
 {
+    if (prm.n_records <= NEAR_MAX_RECORDS && !ctx->local_two_stage) {
+        hipLaunchKernelGGL(k_candidates_near, dim3(1), dim3(TICK_BLOCK), 0, ctx->stream, ctx->db_xy_heading, prm, ctx->cand_ids,
+                           ctx->cand_n, ctx->tick_flags);
+        return;
+    }
     const int L = prm.n_records, k = L < prm.max_candidates * 3 ? L : prm.max_candidates * 3;
     const int nb = L > TOPK_SLICE ? (L + TOPK_SLICE - 1) / TOPK_SLICE : 0;
     if (nb)
@@ -352,8 +420,13 @@ static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t 
 __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
                                                       const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
                                                       const int32_t *__restrict__ f_count, TickParams prm,
-                                                      const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res)
+                                                      const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
+                                                      TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext)
 {
+    // res: the device record (read by the accumulation and by device-side consumers); res_host: the ctx's own record in
+    // pinned host memory, what reloc_tick_result() reads after the stream has drained -- the kernel writes it over PCIe
+    // itself, which takes a 5 us copy kernel (and its launch) out of every synchronous tick; res_ext: a caller-named pinned
+    // record (reloc_tick_result_to), the streaming form of the same.
     const int s = threadIdx.x;
     const int nc = min(*cand_n, MAX_CAND);
     const int nfeat = *f_count;
@@ -409,6 +482,8 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
             out.reproj = 0; out.n_inl = 0; out.lm_idx = -1; out.relocating = relocating; out.n_features = nfeat; out.n_candidates = nc;
             out.outcome = nfeat < prm.min_matches ? RELOC_OUT_NO_FEATURES : (nc == 0 ? RELOC_OUT_NO_CANDIDATES : RELOC_OUT_NO_PNP_ACCEPT);
             *res = out;
+            *res_host = out;
+            if (res_ext) *res_ext = out;
         }
         return;
     }
@@ -421,6 +496,8 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
         const double shift = sqrt(dx * dx + dy * dy);
         out.outcome = (check && shift > prm.consistency_m) ? RELOC_OUT_CONSISTENCY_FAIL : RELOC_OUT_PUBLISHED;
         *res = out;
+        *res_host = out;
+        if (res_ext) *res_ext = out;
     }
 }
 
@@ -463,7 +540,7 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
                                  ctx->prm.ransac_confidence, seed, ctx->prm.min_matches)))
         return rc;
     hipLaunchKernelGGL(k_tick_finalize, dim3(1), dim3(64), 0, st, ctx->cand_ids, ctx->cand_n, ctx->p_out, ctx->db_pose,
-                       ctx->f_count, prm, ctx->tick_flags, ctx->tick_res);
+                       ctx->f_count, prm, ctx->tick_flags, ctx->tick_res, ctx->tick_res_host, ctx->tick_res_ext);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
@@ -564,9 +641,8 @@ RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *
                                 int32_t *outcome, int32_t *n_candidates)
 {
     ARG_CHECK_CTX(ctx, true, "ctx is NULL");
-    TickResult r;
-    HIP_TRY(hipMemcpyAsync(&r, ctx->tick_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const TickResult r = *ctx->tick_res_host;          // written by k_tick_finalize itself (pinned, device-visible)
     if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
     if (n_inl) *n_inl = r.n_inl;
     if (reproj) *reproj = (float)r.reproj;
@@ -578,13 +654,19 @@ RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *
 
 RELOC_API const void *reloc_tick_result_dev(reloc_ctx *ctx) { return ctx ? ctx->tick_res : nullptr; }
 
+RELOC_API int reloc_tick_result_to(reloc_ctx *ctx, void *pinned_record)
+{
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
+    ctx->tick_res_ext = (TickResult *)pinned_record;
+    return RELOC_OK;
+}
+
 RELOC_API int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
                                    int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating)
 {
     ARG_CHECK_CTX(ctx, true, "ctx is NULL");
-    TickResult r;
-    HIP_TRY(hipMemcpyAsync(&r, ctx->tick_res, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const TickResult r = *ctx->tick_res_host;          // written by k_tick_finalize itself (pinned, device-visible)
     if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
     if (n_inl) *n_inl = r.n_inl;
     if (reproj) *reproj = r.reproj;

@@ -100,6 +100,16 @@ class Engine:
     def tick_result_dev(self) -> int:
         return int(self._lib.reloc_tick_result_dev(self._ctx))
 
+    def tick_result_to(self, record: np.ndarray | None):
+        """the ticks enqueued from now on also write their 96-byte result record into `record` (a slice of a pinned() array;
+        None stops it): no copy, complete once the stream has passed the tick (reloc_tick_result_to)"""
+        if record is None:
+            N.check(self._lib.reloc_tick_result_to(self._ctx, None), "reloc_tick_result_to")
+            return
+        if record.nbytes < 96 or not record.flags.c_contiguous:
+            raise N.RelocError("tick_result_to: need a contiguous record of at least 96 bytes")
+        N.check(self._lib.reloc_tick_result_to(self._ctx, C.c_void_p(record.ctypes.data)), "reloc_tick_result_to")
+
     def d2h(self, dst: np.ndarray, src_dev: int):
         assert dst.flags["C_CONTIGUOUS"]
         N.check(self._lib.reloc_d2h(self._ctx, N.ptr(dst), C.c_void_p(src_dev), dst.nbytes), "reloc_d2h")
