@@ -235,10 +235,21 @@ int main()
     (void)hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
     std::vector<Variant> vs;
     if (getenv("EXP_COMPUTE")) {
-        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8acc pinned", A, B, out, F, K, 6));
-        vs.push_back(make<0, 3, 8, 8, 1>("full nt(sgpr base) 8acc pinned", A, B, out, F, K, 6));
-        vs.push_back(make<0, 3, 8, 8, 1>("full nt(sgpr base) 8acc pinned", A, B, out, F, K, 5));
-        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8acc pinned", A, B, out, F, K, 5));
+        // order of the 8 distance chains of a lane (the round's main finding), without and with the store
+        vs.push_back(make<1, 0, 2, 8, 1>("compute-only 2 chains (il2)", A, B, out, F, K, 5));
+        vs.push_back(make<1, 0, 4, 8, 1>("compute-only 4 chains (il4)", A, B, out, F, K, 5));
+        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8 chains pinned", A, B, out, F, K, 5));
+        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8 chains pinned", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8 chains pinned", A, B, out, F, K, 7));
+        vs.push_back(make<1, 0, 9, 8, 1>("compute-only 8 chains, compiler's order", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 10, 8, 1>("compute-only 8 chains, xor one step ahead", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 11, 8, 1>("compute-only 8 chains, 2 xor then 2 bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 16, 8, 1>("compute-only 16 chains pinned (2x work)", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 2, 8, 1>("full nt 2 chains (il2)", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8 chains pinned", A, B, out, F, K, 5));
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8 chains pinned", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8 chains pinned", A, B, out, F, K, 7));
+        vs.push_back(make<0, 3, 8, 8, 1>("full nt (sgpr row base) 8 chains pinned", A, B, out, F, K, 6));
     } else {
     vs.push_back(make<0, 0, 1, 8, 1>("full plain serial (r1 kernel)", A, B, out, F, K, 6));
     vs.push_back(make<0, 1, 1, 8, 1>("full nt serial", A, B, out, F, K, 6));

@@ -16,7 +16,7 @@ O.build()
 e = Engine(0, 1280, 720, 8192)
 rng = np.random.default_rng(args.seed)
 t_end = time.time() + args.seconds
-n_case = {"match": 0, "knn": 0, "db": 0, "ratio": 0, "matrix": 0, "orb": 0, "pnp": 0, "record": 0}
+n_case = {"match": 0, "knn": 0, "db": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
 
 
 def descs(n, dup_p=0.1, low_entropy=False):
@@ -82,6 +82,22 @@ while time.time() < t_end:
         for f in ("xy", "angle", "response", "size"):
             if not np.array_equal(g[f].view(np.uint32), x[f][:k].view(np.uint32)): fail(kind, (w, h, nf, f))
         if not (np.array_equal(g["desc"], x["desc"][:k]) and np.array_equal(g["octave"], x["octave"][:k])): fail(kind, (w, h, nf, "desc"))
+    elif kind == "orb_bgr":       # the tick's input form: interleaved 3-channel frame in device memory, any width / row stride
+        w, h = int(rng.integers(64, 1281)), int(rng.integers(64, 721))
+        img = synth.textured_frame(rng, w, h, n_shapes=int(rng.integers(5, max(6, w * h // 600))), noise=float(rng.choice([0, 1, 4, 12])))
+        stride = 3 * w + int(rng.choice([0, 0, 1, 2, 3, 4, 13]))
+        raw = np.zeros((h, stride), np.uint8); raw[:, :3 * w] = img.reshape(h, 3 * w)
+        order = bool(rng.integers(0, 2))
+        dev = e.dev_alloc(raw.nbytes)
+        e.h2d(dev, raw)
+        n = e.orb_frame_dev(dev, w, h, stride, order_rgb=order)
+        e.dev_free(dev)
+        gray = O.gray_u8(img, order)
+        pyr = O.pyramid(gray)
+        for l in range(8):
+            if not np.array_equal(e.frame_debug_plane(0, l), pyr[l]): fail(kind, (w, h, stride, order, "level", l))
+        x = O.orb_detect_compute(gray, 500, max_out=e.max_feat)
+        if n != min(x["n"], e.max_feat): fail(kind, (w, h, stride, order, n, x["n"]))
     elif kind == "pnp":
         m = int(rng.integers(4, 800))
         obj, img, rv, tv, inl = synth.pnp_problem(rng, m=m, outlier_ratio=float(rng.uniform(0, 0.7)), noise_px=float(rng.choice([0, 0.3, 1.0])))
