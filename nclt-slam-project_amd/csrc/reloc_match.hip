@@ -649,6 +649,8 @@ __global__ __launch_bounds__(64 * SQ_WAVES) void k_db_scan_rows(const uint4 *__r
             u32 rbest = 0xFFFFFFFFu;
             for (int q0 = 0; q0 < C; q0 += G) {
                 u32 ck[G];
+                // (G pinned accumulator chains as in ham8_cols, query words as SGPR operands: measured slower here, 19.9 vs 17.8 us
+                // at Q = 32 -- this kernel waits on its row loads, not on the v_bcnt chain)
 #pragma unroll
                 for (int j = 0; j < G; ++j) {
                     const int q = min(q0 + j, C - 1);   // wave-uniform; repeats of the last query lose every tie (larger index)

@@ -348,11 +348,29 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_near(const double *__
     __syncthreads();
     // LocalKey's distance field is 0xFFFFFFFFFFF - trunc44(d): "trunc44(d) <= trunc44(r)" is "key field >= that of r"
     const unsigned long long rfield = 0xFFFFFFFFFFFull - ((unsigned long long)__double_as_longlong(prm.radius_m) >> 20);
-    for (int i = tid; i < L; i += TICK_BLOCK) {
-        const unsigned long long key = keyfn(i);
-        if ((key >> 20) >= rfield) {
-            const int at = atomicAdd(&s_cnt, 1);
-            if (at < NEAR_CAP) s_near[at] = key;
+    // 8 records per thread and turn, their loads issued together: the walk is a chain of memory round trips otherwise
+    constexpr int NEAR_UNROLL = 8;
+    for (int i0 = tid; i0 < L; i0 += NEAR_UNROLL * TICK_BLOCK) {
+        double rx[NEAR_UNROLL], ry[NEAR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < NEAR_UNROLL; ++u) {
+            const int i = min(i0 + u * TICK_BLOCK, L - 1);
+            rx[u] = xyh[4 * i];
+            ry[u] = xyh[4 * i + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < NEAR_UNROLL; ++u) {
+            const int i = i0 + u * TICK_BLOCK;
+            if (i >= L) break;
+            // = LocalKey(i), from the values already loaded
+            const double dx = rx[u] - vx, dy = ry[u] - vy;
+            const double d = sqrt(dx * dx + dy * dy);
+            const unsigned long long q = (unsigned long long)__double_as_longlong(d) >> 20;
+            const unsigned long long key = ((0xFFFFFFFFFFFull - q) << 20) | (unsigned long long)(0xFFFFF - (i & 0xFFFFF));
+            if ((key >> 20) >= rfield) {
+                const int at = atomicAdd(&s_cnt, 1);
+                if (at < NEAR_CAP) s_near[at] = key;
+            }
         }
     }
     __syncthreads();
