@@ -282,7 +282,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // descriptors kept ONCE per workgroup in LDS (two conflict-free 16-byte planes) and streamed column by column against 4-8
 // teach rows held in SGPRs -- 58 VGPRs, 8 waves per SIMD, 512-thread workgroups, same 20 instructions per pair: 176 vs
 // 170 us at 10 000 records, 1533 vs 1497 us at 100 000.  Occupancy is not what holds this kernel back.
-template <int NJ, bool EMIT>
+template <int NJ, bool EMIT, int NW = 4>
 __device__ __forceinline__ void db_scan_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
@@ -315,9 +315,10 @@ __device__ __forceinline__ void db_scan_body(
             q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
         }
     };
-    const bool bound = (4 % ncb) == 0;            // ncb in {1, 2, 4}: static wave -> column block binding
+    static_assert(NW == 4 || NW == 8, "wsum[8] is the ticket slot");
+    const bool bound = (NW % ncb) == 0;           // ncb divides the wave count: static wave -> column block binding
     const int my_cb = bound ? wave % ncb : 0;
-    const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? 4 / ncb : 4;
+    const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? NW / ncb : NW;
     // RELOC_TICK_AUTO: this scan stands down (scan-uniform).  Its workgroups still check out at the end, so that the last
     // workgroup of the launch can put the counters back
     const bool stand_down = mask.skip_if && *mask.skip_if != 0;
@@ -388,8 +389,8 @@ __device__ __forceinline__ void db_scan_body(
         const int64_t row0 = off[r];
         const int n = (int)(off[r + 1] - row0);
         const uint4 *rec = db + 2 * row0;
-        for (int i = tid; i < ncb * CB; i += 256) colbest[i] = 0xFFFFFFFFu;
-        for (int i = tid; i < n; i += 256) rowkey[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < ncb * CB; i += 64 * NW) colbest[i] = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += 64 * NW) rowkey[i] = 0xFFFFFFFFu;
         __syncthreads();
         if (n > 0 && C > 0) {
             for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
@@ -415,7 +416,7 @@ __device__ __forceinline__ void db_scan_body(
         __syncthreads();
         // mutual resolution, in teach-row (queryIdx) order
         u32 base = 0;
-        for (int rb = 0; rb < n; rb += 256) {
+        for (int rb = 0; rb < n; rb += 64 * NW) {
             const int row = rb + tid;
             bool mutual = false;
             u32 key = 0;
@@ -430,7 +431,7 @@ __device__ __forceinline__ void db_scan_body(
             u32 before = base;
             for (int w = 0; w < wave; ++w) before += wsum[w];
             u32 total = 0;
-            for (int w = 0; w < 4; ++w) total += wsum[w];
+            for (int w = 0; w < NW; ++w) total += wsum[w];
             if (EMIT && mutual) {
                 const u32 pos = before + (u32)__popcll(bal & ((1ull << lane) - 1ull));
                 const int64_t o = (int64_t)it * emit_stride + pos;
@@ -467,8 +468,8 @@ __device__ __forceinline__ void db_scan_body(
 // that is enough, so their cost follows the query count instead of being flat below 512; the fused tick passes
 // its feature capacity and always runs NJ = 8.  (One kernel branching on the device-side count was measured:
 // it costs the NJ = 8 path 3 %.)
-template <int NJ, bool EMIT>
-__global__ __launch_bounds__(256, 4) void k_db_scan(
+template <int NJ, bool EMIT, int NW>
+__global__ __launch_bounds__(64 * NW, 16 / NW) void k_db_scan(
     const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
@@ -477,8 +478,8 @@ __global__ __launch_bounds__(256, 4) void k_db_scan(
 {
     extern __shared__ u32 lds[];
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
-    db_scan_body<NJ, EMIT>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
-                           emit_stride, mask, ticket, quota);
+    db_scan_body<NJ, EMIT, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
+                               emit_stride, mask, ticket, quota);
 }
 
 // Several frames in ONE launch (BASELINE.json config 4: batched relocalization): workgroup b scans frame b % B -- its
@@ -738,14 +739,17 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         if (ctx->scan_gens < 0) { quota = 0; grid = ctx->num_cu * (ctx->scan_gens <= -2 ? -ctx->scan_gens - 1 : 4); }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
     }
     if (grid > n_ids_max) grid = n_ids_max;
-#define RELOC_LAUNCH_SCAN(NJ, EMIT)                                                                                          \
-    hipLaunchKernelGGL((k_db_scan<NJ, EMIT>), dim3(grid), dim3(256), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
+    // Match lists of a few candidate records (the tick's emit pass, reloc_match_mutual): one workgroup per record is
+    // alone on its CU, one wave per SIMD issues an instruction only every ~7 cycles, so the record's rows are the
+    // kernel's run time -- 8 waves (two per SIMD, 8 rows each at 64 rows) instead of 4: 13.5 -> ~9 us for 25 candidates.
+#define RELOC_LAUNCH_SCAN(NJ, EMIT, NW)                                                                                      \
+    hipLaunchKernelGGL((k_db_scan<NJ, EMIT, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
                        m_n, emit_stride, mask, ticket, quota)
     if (m_qidx) {
-        if (nj == 2) RELOC_LAUNCH_SCAN(2, true); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true); else RELOC_LAUNCH_SCAN(8, true);
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 8); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 8); else RELOC_LAUNCH_SCAN(8, true, 8);
     } else {
-        if (nj == 2) RELOC_LAUNCH_SCAN(2, false); else if (nj == 4) RELOC_LAUNCH_SCAN(4, false); else RELOC_LAUNCH_SCAN(8, false);
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, false, 4); else if (nj == 4) RELOC_LAUNCH_SCAN(4, false, 4); else RELOC_LAUNCH_SCAN(8, false, 4);
     }
 #undef RELOC_LAUNCH_SCAN
     HIP_TRY(hipGetLastError());

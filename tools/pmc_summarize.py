@@ -11,7 +11,7 @@ doubled value ("upper") are kept; bench.py picks per kernel.
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-KERNELS = {"k_db_scan": r"k_db_scan<(8, )?false>", "k_hamming_matrix": r"k_hamming_matrix\("}
+KERNELS = {"k_db_scan": r"k_db_scan<(8, )?false(, 4)?>", "k_hamming_matrix": r"k_hamming_matrix\("}
 NAMES = {"FETCH_SIZE": "fetch_size_raw_bytes", "WRITE_SIZE": "write_size_bytes", "SQ_INSTS_VALU": "valu_wave_insts",
          "GRBM_GUI_ACTIVE": "grbm_gui_active_sum", "SQ_WAVE_CYCLES": "sq_wave_cycles", "SQ_WAIT_ANY": "sq_wait_any",
          "SQ_WAIT_INST_ANY": "sq_wait_inst_any", "SQ_ACTIVE_INST_ANY": "sq_active_inst_any", "SQ_WAVES": "waves",
