@@ -502,8 +502,14 @@ __device__ bool chol_solve6(const double Ain[36], const double b[6], double x[6]
     return true;
 }
 
-// grid n_cand_max, block 64
-__global__ __launch_bounds__(64) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
+// grid n_cand_max, block 64.  Register budget: left alone the kernel takes 237 VGPRs, and a wave of that size only starts on a
+// SIMD from which TWO scan waves have retired; held to 128 (4 waves per SIMD, 144 bytes of scratch) it fits when one has:
+// 4-stream run 5940 -> 6020 frames/s, synchronous tick +1.7 us.  80 registers: no further gain, tick +16 us.
+// (The same limit on k_pnp_hyp (108 -> 80) and k_pyramid (81 -> 64) changes nothing.)
+#ifndef PNP_FINISH_WAVES
+#define PNP_FINISH_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PNP_FINISH_WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
                                                    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                    PnpParams prm, const double *__restrict__ Rt_all,
                                                    const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
