@@ -94,6 +94,10 @@ __device__ __forceinline__ void ham8x2(const u32 q0[8], const u32 q1[8], const u
 //   16 chains                                                           same as 8
 // i.e. a v_bcnt must not read the accumulator a v_bcnt wrote fewer than ~16 instructions earlier, while the xor -> bcnt
 // pair itself wants to stay adjacent.  The compiler's scheduler, left free with the same 8 accumulators, produces 187 us.
+// One statement per INSTRUCTION on purpose: the compiler then puts an `s_nop 0` between each xor and its bcnt (61 per
+// row), and that spacing is part of the result -- the same order written as one asm block per word, same run, whole
+// matrix kernel: xor; bcnt back to back 202 us, xor; s_nop 0; bcnt 188, xor; bcnt; s_nop 0 186, this form 177
+// (profiles/r2_exp_matrix2_spacing.log); in k_db_scan the block form without the s_nop costs 170.7 vs 161.0 us.
 template <int NC>
 __device__ __forceinline__ void ham8_cols(const u32 (&q)[NC][8], const u32 (&w)[8], u32 (&h)[NC])
 {

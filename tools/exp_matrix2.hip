@@ -17,6 +17,37 @@ __device__ __forceinline__ u32 ham8(const u32 q[8], const uint4 a, const uint4 b
     acc = bcnt_acc(q[4] ^ b.x, acc); acc = bcnt_acc(q[5] ^ b.y, acc); acc = bcnt_acc(q[6] ^ b.z, acc); acc = bcnt_acc(q[7] ^ b.w, acc);
     return acc;
 }
+
+// one word of the 8 chains as ONE asm block (no compiler-inserted s_nop): PRE = text between an xor and its bcnt,
+// POST = text after the bcnt
+#define WORD_BLOCK(PRE, POST, ACC_IN)                                                                                      \
+    asm volatile("v_xor_b32 %8, %16, %17\n\t" PRE "v_bcnt_u32_b32 %0, %8, " ACC_IN("%0") "\n\t" POST                        \
+                 "v_xor_b32 %9, %16, %18\n\t" PRE "v_bcnt_u32_b32 %1, %9, " ACC_IN("%1") "\n\t" POST                        \
+                 "v_xor_b32 %10, %16, %19\n\t" PRE "v_bcnt_u32_b32 %2, %10, " ACC_IN("%2") "\n\t" POST                      \
+                 "v_xor_b32 %11, %16, %20\n\t" PRE "v_bcnt_u32_b32 %3, %11, " ACC_IN("%3") "\n\t" POST                      \
+                 "v_xor_b32 %12, %16, %21\n\t" PRE "v_bcnt_u32_b32 %4, %12, " ACC_IN("%4") "\n\t" POST                      \
+                 "v_xor_b32 %13, %16, %22\n\t" PRE "v_bcnt_u32_b32 %5, %13, " ACC_IN("%5") "\n\t" POST                      \
+                 "v_xor_b32 %14, %16, %23\n\t" PRE "v_bcnt_u32_b32 %6, %14, " ACC_IN("%6") "\n\t" POST                      \
+                 "v_xor_b32 %15, %16, %24\n\t" PRE "v_bcnt_u32_b32 %7, %15, " ACC_IN("%7") "\n\t" POST                      \
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]),          \
+                   "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)                  \
+                 : "s"(rw[q]), "v"(b[0][q]), "v"(b[1][q]), "v"(b[2][q]), "v"(b[3][q]), "v"(b[4][q]), "v"(b[5][q]), "v"(b[6][q]), \
+                   "v"(b[7][q]))
+#define ACC_SELF(r) r
+
+// the same with ONE temporary for all eight xor results (what the compiler does with a statement per instruction)
+#define WORD_BLOCK1(PRE, POST)                                                                                             \
+    asm volatile("v_xor_b32 %8, %9, %10\n\t" PRE "v_bcnt_u32_b32 %0, %8, %0\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %11\n\t" PRE "v_bcnt_u32_b32 %1, %8, %1\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %12\n\t" PRE "v_bcnt_u32_b32 %2, %8, %2\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %13\n\t" PRE "v_bcnt_u32_b32 %3, %8, %3\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %14\n\t" PRE "v_bcnt_u32_b32 %4, %8, %4\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %15\n\t" PRE "v_bcnt_u32_b32 %5, %8, %5\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %16\n\t" PRE "v_bcnt_u32_b32 %6, %8, %6\n\t" POST                                      \
+                 "v_xor_b32 %8, %9, %17\n\t" PRE "v_bcnt_u32_b32 %7, %8, %7\n\t" POST                                      \
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "=&v"(x0) \
+                 : "s"(rw[q]), "v"(b[0][q]), "v"(b[1][q]), "v"(b[2][q]), "v"(b[3][q]), "v"(b[4][q]), "v"(b[5][q]), "v"(b[6][q]), \
+                   "v"(b[7][q]))
 // MODE 0 full, 1 compute only (store behind a never-true test), 2 store only (no distances)
 // ST    0 plain store, 1 nontemporal, 2 sc1 (write-through) via inline asm
 // IL    1 serial chains, 2 two packed registers interleaved
@@ -77,6 +108,26 @@ __global__ __launch_bounds__(256, WPS) void k(const uint4 *__restrict__ A, int64
                             o[c] = bcnt_acc(x, o[c]);
                         }
                     }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
+            } else if (IL >= 20 && IL <= 30) {
+                const u32 rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                u32 o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                u32 x0, x1, x2, x3, x4, x5, x6, x7;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (IL == 20) WORD_BLOCK("", "", ACC_SELF);
+                    if (IL == 21) WORD_BLOCK("s_nop 0\n\t", "", ACC_SELF);
+                    if (IL == 22) WORD_BLOCK("s_nop 1\n\t", "", ACC_SELF);
+                    if (IL == 23) WORD_BLOCK("", "s_nop 0\n\t", ACC_SELF);
+                    if (IL == 24) WORD_BLOCK("s_nop 0\n\t", "s_nop 0\n\t", ACC_SELF);
+                    if (IL == 25) WORD_BLOCK("s_nop 2\n\t", "", ACC_SELF);
+                    if (IL == 26) WORD_BLOCK("v_nop\n\t", "", ACC_SELF);
+                    if (IL == 27) WORD_BLOCK1("s_nop 0\n\t", "");
+                    if (IL == 28) WORD_BLOCK1("", "s_nop 0\n\t");
+                    if (IL == 29) WORD_BLOCK1("", "");
+                    if (IL == 30) WORD_BLOCK1("s_nop 0\n\t", "s_nop 0\n\t");
+                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) w[p] = o[2 * p] | (o[2 * p + 1] << 16);
             } else if (IL == 16) {
@@ -234,7 +285,20 @@ int main()
     (void)hipMalloc(&A, F * 32); (void)hipMalloc(&B, K * 32); (void)hipMalloc(&out, F * K * 2 + 4096);
     (void)hipMemcpy(A, h.data(), F * 32, hipMemcpyHostToDevice); (void)hipMemcpy(B, h.data(), K * 32, hipMemcpyHostToDevice);
     std::vector<Variant> vs;
-    if (getenv("EXP_COMPUTE")) {
+    if (getenv("EXP_SPACING")) {
+        // what stands between an xor and its dependent bcnt (whole word as one asm block: nothing inserted by the compiler)
+        vs.push_back(make<0, 1, 8, 8, 1>("full nt 8 chains, statement per instr (compiler s_nop)", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 20, 8, 1>("full nt block 8 temps: xor; bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 21, 8, 1>("full nt block 8 temps: xor; s_nop 0; bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 23, 8, 1>("full nt block 8 temps: xor; bcnt; s_nop 0", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 29, 8, 1>("full nt block 1 temp: xor; bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 27, 8, 1>("full nt block 1 temp: xor; s_nop 0; bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 28, 8, 1>("full nt block 1 temp: xor; bcnt; s_nop 0", A, B, out, F, K, 6));
+        vs.push_back(make<0, 1, 30, 8, 1>("full nt block 1 temp: xor; s_nop 0; bcnt; s_nop 0", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 8, 8, 1>("compute-only 8 chains, statement per instr", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 27, 8, 1>("compute-only block 1 temp: xor; s_nop 0; bcnt", A, B, out, F, K, 6));
+        vs.push_back(make<1, 0, 28, 8, 1>("compute-only block 1 temp: xor; bcnt; s_nop 0", A, B, out, F, K, 6));
+    } else if (getenv("EXP_COMPUTE")) {
         // order of the 8 distance chains of a lane (the round's main finding), without and with the store
         vs.push_back(make<1, 0, 2, 8, 1>("compute-only 2 chains (il2)", A, B, out, F, K, 5));
         vs.push_back(make<1, 0, 4, 8, 1>("compute-only 4 chains (il4)", A, B, out, F, K, 5));
@@ -265,6 +329,7 @@ int main()
     vs.push_back(make<2, 1, 1, 8, 1>("store-only nt", A, B, out, F, K, 5));
     vs.push_back(make<2, 0, 1, 8, 1>("store-only plain", A, B, out, F, K, 5));
     }
+    for (int i = 0; i < 100; ++i) vs[0].once();                // pre-roll: ~80 ms of load, the clocks settle
     for (auto &v : vs) v.once();                               // warm-up
     for (int round = 0; round < 15; ++round)                    // interleaved rounds: drift of the clock hits all variants alike
         for (auto &v : vs) v.t.push_back(v.once());
