@@ -101,15 +101,15 @@ __device__ __forceinline__ void ham8x2(const u32 q0[8], const u32 q1[8], const u
 template <int NC>
 __device__ __forceinline__ void ham8_cols(const u32 (&q)[NC][8], const u32 (&w)[8], u32 (&h)[NC])
 {
-#pragma unroll
-    for (int j = 0; j < NC; ++j) h[j] = 0;
+    // the first word starts each accumulator from the inline constant 0 (no v_mov per chain and row: 158.7 -> 156.3 us)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
             u32 x;
             asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(w[k]), "v"(q[j][k]));
-            asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h[j]) : "v"(x));
+            if (k == 0) asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(h[j]) : "v"(x));
+            else asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h[j]) : "v"(x));
         }
 }
 
@@ -207,8 +207,9 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
     // compile-time row and column indices: the key constants are immediates.
     // (Measured and dropped: row i-1's bookkeeping software-pipelined INTO row i's distance chains, one 16-bit instruction
-    // in every second xor/bcnt slot, all pinned with asm volatile -- 164.9 vs 163.7 us at 10 000 records, 1410 vs 1368 us at
-    // 100 000: full-rate instructions are not free between half-rate v_bcnt, the wave's issue slots are what is spent.)
+    // in every second xor/bcnt slot, all pinned with asm volatile -- behind the bcnt: 164.9 vs 163.7 us at 10 000 records,
+    // 1410 vs 1368 us at 100 000; between the xor and its bcnt, where the plain form has the compiler's s_nop: 163.8 vs
+    // 161.1 and 1381 vs 1358.  Full-rate instructions are not free between half-rate v_bcnt.)
     static_for<R>([&](auto ic_) {
         constexpr int i = decltype(ic_)::value;
         constexpr int t = [](int v) { int r = 0; for (int bb = 0; bb < LOG_R; ++bb) r |= ((v >> bb) & 1) << (LOG_R - 1 - bb); return r; }(i);
