@@ -179,10 +179,17 @@ def test_batched_tick_one_scan_launch_for_several_frames(engine, config4):
         e.db_share(engine)
         e.set_stream(engine.stream_ptr)
     fdev = [engine.to_device(f) for f in frames]
+    recs = engine.pinned((8, 96), np.uint8)                    # one pinned result record per frame (reloc_tick_result_to)
     for n in (8, 3, 8):
+        recs[...] = 0xEE
+        for f in range(n):
+            es[f].tick_result_to(recs[f])
         Engine.tick_batch_dev(es[:n], fdev[:n], 640, 480, base_poses[:n], global_reloc=True, seeds=[100 + f for f in range(n)])
         for f in range(n):
             got, (exp, dbg) = es[f].tick_result(), ref[f]
+            r = recs[f].view(np.int32)
+            assert (r[16], r[17], r[18], r[19]) == (got["n_inliers"], got["lm_idx"], got["outcome"], got["n_candidates"]), (n, f)
+            np.testing.assert_array_equal(recs[f, :56].view(np.float64), np.asarray(got["anchor_pose"], np.float64))
             assert got["outcome"] == exp["outcome"] and got["n_inliers"] == exp["n_inliers"] and got["lm_idx"] == exp["lm_idx"], (n, f)
             assert got["n_candidates"] == exp["n_candidates"]
             np.testing.assert_allclose(got["anchor_pose"], exp["anchor_pose"], atol=1e-9)
@@ -190,6 +197,8 @@ def test_batched_tick_one_scan_launch_for_several_frames(engine, config4):
     # a single-context scan afterwards still works (counters were reset by the batched launches)
     r = engine.tick(frames[2], base_poses[2], global_reloc=True, seed=102)
     assert r["lm_idx"] == ref[2][0]["lm_idx"] and r["n_inliers"] == ref[2][0]["n_inliers"]
+    for e in es:
+        e.tick_result_to(None)
     for p in fdev:
         engine.dev_free(p)
     for e in es[1:]:
