@@ -20,4 +20,17 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 300 python bench.py --streams 1 --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_1stream.json
 timeout -k 10 300 python bench.py --size 720p --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_720p.json
 timeout -k 10 400 python tools/microbench.py > $O/microbench.jsonl 2>$O/microbench.err || true
+# variant / experiment logs that DESIGN.md cites (developer harnesses; each a few seconds)
+if [ -x tools/exp_matrix2 ]; then
+  EXP_COMPUTE=1 timeout -k 10 300 ./tools/exp_matrix2 > $O/exp_matrix2_chains.log 2>&1 || true
+  EXP_SPACING=1 timeout -k 10 300 ./tools/exp_matrix2 > $O/exp_matrix2_spacing.log 2>&1 || true
+fi
+timeout -k 10 120 python tools/exp_matrix_prod.py > $O/matrix_prod_series.log 2>&1 || true
+timeout -k 10 300 python tools/exp_stage_throughput.py 4 > $O/stage_throughput.log 2>&1 || true
+timeout -k 10 400 python bench.py --shard-db --records 100000 --steps 10 2>/dev/null | tail -1 > $O/bench_shard100k.json || true
+timeout -k 10 300 python bench.py --shard-db --steps 30 2>/dev/null | tail -1 > $O/bench_shard10k.json || true
+timeout -k 10 300 python bench.py --matrix-only --steps 200 2>/dev/null | tail -1 > $O/bench_matrix_only.json || true
+# the multi-rank code paths with two ranks on this ONE GPU (gloo; not a scaling number)
+timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --backend gloo --rehearse --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_rehearsal.json || true
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || true
 echo collected
