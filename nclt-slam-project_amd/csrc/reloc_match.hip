@@ -746,18 +746,18 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (grid > n_ids_max) grid = n_ids_max;
     // Match lists of a few candidate records (the tick's emit pass, reloc_match_mutual): one workgroup per record is
     // alone on its CU and one wave per SIMD issues an instruction only every ~7 cycles, so the record's rows are the
-    // kernel's run time.  8 waves per record (NW = 8, -DRELOC_EMIT_WAVES=8) take the synchronous tick from 322 / 152 to
-    // 318 / 149 us (global / local) -- and the 4-stream throughput from 5940 to 5360 frames/s: a 512-thread workgroup of
-    // this register size needs TWO scan workgroups of one CU to retire before it fits.  4 waves it stays.
+    // kernel's run time.  8 waves per record take the synchronous tick from 322 / 152 to 318 / 149 us (global / local) --
+    // and the 4-stream whole-database run from 5940 to 5360 frames/s: a 512-thread workgroup of this register size needs
+    // TWO scan workgroups of one CU to retire before it fits.  So: 8 waves where no scan runs beside it (local-candidate
+    // ticks, single calls: ctx->latency_shapes), 4 waves in ticks that scan the database.
 #define RELOC_LAUNCH_SCAN(NJ, EMIT, NW)                                                                                      \
     hipLaunchKernelGGL((k_db_scan<NJ, EMIT, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
                        m_n, emit_stride, mask, ticket, quota)
-#ifndef RELOC_EMIT_WAVES
-#define RELOC_EMIT_WAVES 4
-#endif
-    if (m_qidx) {
-        if (nj == 2) RELOC_LAUNCH_SCAN(2, true, RELOC_EMIT_WAVES); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, RELOC_EMIT_WAVES); else RELOC_LAUNCH_SCAN(8, true, RELOC_EMIT_WAVES);
+    if (m_qidx && ctx->latency_shapes) {
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 8); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 8); else RELOC_LAUNCH_SCAN(8, true, 8);
+    } else if (m_qidx) {
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 4); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 4); else RELOC_LAUNCH_SCAN(8, true, 4);
     } else {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, false, 4); else if (nj == 4) RELOC_LAUNCH_SCAN(4, false, 4); else RELOC_LAUNCH_SCAN(8, false, 4);
     }
@@ -1080,9 +1080,11 @@ RELOC_API int reloc_match_mutual(reloc_ctx *ctx, const uint8_t *q, int nq, const
     HIP_TRY(hipMemcpyAsync(doff, offs, sizeof(offs), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_db_scan(ctx, (const uint8_t *)dq, doff, 1, nullptr, nullptr, 1, (const uint8_t *)dt, nullptr, nt,
-                             nq, nullptr, dqi, dti, ddi, dn, nq)))
-        return rc;
+    ctx->latency_shapes = true;                               // a single record, nothing runs beside it: 8 waves
+    rc = launch_db_scan(ctx, (const uint8_t *)dq, doff, 1, nullptr, nullptr, 1, (const uint8_t *)dt, nullptr, nt,
+                        nq, nullptr, dqi, dti, ddi, dn, nq);
+    ctx->latency_shapes = false;
+    if (rc) return rc;
     int32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -503,13 +503,12 @@ __device__ bool chol_solve6(const double Ain[36], const double b[6], double x[6]
 }
 
 // grid n_cand_max, block 64.  Register budget: left alone the kernel takes 237 VGPRs, and a wave of that size only starts on a
-// SIMD from which TWO scan waves have retired; held to 128 (4 waves per SIMD, 144 bytes of scratch) it fits when one has:
+// SIMD from which TWO scan waves have retired; held to 128 (WAVES = 4 per SIMD, 144 bytes of scratch) it fits when one has:
 // 4-stream run 5940 -> 6020 frames/s, synchronous tick +1.7 us.  80 registers: no further gain, tick +16 us.
-// (The same limit on k_pnp_hyp (108 -> 80) and k_pyramid (81 -> 64) changes nothing.)
-#ifndef PNP_FINISH_WAVES
-#define PNP_FINISH_WAVES 4
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PNP_FINISH_WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
+// (The same limit on k_pnp_hyp (108 -> 80) and k_pyramid (81 -> 64) changes nothing.)  Ticks that run no whole-database scan
+// and the single-call entry point use the unconstrained instantiation (ctx->latency_shapes).
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
                                                    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                    PnpParams prm, const double *__restrict__ Rt_all,
                                                    const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
@@ -661,8 +660,12 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
                        ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt);
     hipLaunchKernelGGL(k_pnp_score, dim3(iters, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
                        n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, (uint8_t *)nullptr, MAX_HYP);
-    hipLaunchKernelGGL(k_pnp_finish, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
-                       n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
+    if (ctx->latency_shapes)
+        hipLaunchKernelGGL(k_pnp_finish<1>, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
+                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
+    else
+        hipLaunchKernelGGL(k_pnp_finish<4>, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
+                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
     reloc_prof_end(ctx, RELOC_PROF_PNP);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
@@ -717,7 +720,10 @@ RELOC_API int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *im
     HIP_TRY(hipMemcpyAsync(ctx->m_n, &m, 4, hipMemcpyHostToDevice, ctx->stream));
     // the single-call path has no MIN_MATCHES gate (that gate belongs to the matcher, M:330)
     int rc;
-    if ((rc = pnp_run_candidates(ctx, 1, nullptr, K4, iters, thr_px, conf, seed, RELOC_PNP_SAMPLE))) return rc;
+    ctx->latency_shapes = true;
+    rc = pnp_run_candidates(ctx, 1, nullptr, K4, iters, thr_px, conf, seed, RELOC_PNP_SAMPLE);
+    ctx->latency_shapes = false;
+    if (rc) return rc;
     PnpOut po;
     HIP_TRY(hipMemcpyAsync(&po, ctx->p_out, sizeof(po), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -550,13 +550,16 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
     emit.xyh = nullptr;
     emit.q[0] = emit.q[1] = emit.q[2] = 0; emit.q[3] = 1;
     emit.g_pts3d = ctx->db_pts3d; emit.g_xy = ctx->f_xy; emit.g_obj = ctx->p_obj; emit.g_img = ctx->p_img;
-    if ((rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
-                             ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
-                             ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit)))
-        return rc;
-    if ((rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, ctx->prm.ransac_iterations, (float)ctx->prm.ransac_reproj_px,
-                                 ctx->prm.ransac_confidence, seed, ctx->prm.min_matches)))
-        return rc;
+    // a tick of local candidates runs no whole-database scan: its emit pass and refinement are sized for latency
+    ctx->latency_shapes = prm.mode == RELOC_TICK_LOCAL;
+    rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
+                        ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
+                        ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit);
+    if (!rc)
+        rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, ctx->prm.ransac_iterations, (float)ctx->prm.ransac_reproj_px,
+                                ctx->prm.ransac_confidence, seed, ctx->prm.min_matches);
+    ctx->latency_shapes = false;
+    if (rc) return rc;
     hipLaunchKernelGGL(k_tick_finalize, dim3(1), dim3(64), 0, st, ctx->cand_ids, ctx->cand_n, ctx->p_out, ctx->db_pose,
                        ctx->f_count, prm, ctx->tick_flags, ctx->tick_res, ctx->tick_res_host, ctx->tick_res_ext);
     HIP_TRY(hipGetLastError());
