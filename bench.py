@@ -442,11 +442,13 @@ def main():
         orb_ms, orb_n = e.profile_get(2)
         pnp_ms, pnp_n = e.profile_get(3)
         e.profile_enable(False)
-        # single-stream synchronous tick latency (enqueue + kernels + result record in host memory), global and local candidate search
+        # single-stream synchronous tick latency (enqueue + kernels + result record in host memory), global and local candidate
+        # search, with the context told that it is alone on the GPU (reloc_set_exclusive; the timed 4-stream runs above are not)
         lat = {}
         for mode, name in ((1, "tick_global"), (0, "tick_local")):
             ts_ = []
             e.tick_result_to(results[0])
+            e.set_exclusive(True)                                         # a synchronous single-stream loop: the deployment this hint is for
             for i in range(120):
                 results[0, 72:76] = 255                                    # outcome field: overwritten by the tick
                 t0 = time.perf_counter()
@@ -454,6 +456,7 @@ def main():
                 e.sync()                                                  # the result record is in host memory now
                 ts_.append(time.perf_counter() - t0)
                 assert results[0, 72] != 255, "tick result record did not arrive"
+            e.set_exclusive(False)
             ts_ = np.array(ts_[20:]) * 1e6
             lat[name + "_us"] = dict(median=float(np.median(ts_)), p95=float(np.percentile(ts_, 95)))
         desc, pts, off, poses = db

@@ -70,6 +70,7 @@ SIGNATURES = {
     "reloc_get_stream": (P, [c_ctx]),
     "reloc_tick_result_dev": (P, [c_ctx]),
     "reloc_tick_result_to": (C.c_int, [c_ctx, P]),
+    "reloc_set_exclusive": (C.c_int, [c_ctx, C.c_int]),
     "reloc_db_fetch": (C.c_int, [c_ctx, i64, P, P, P, P, P, P]),
     "reloc_tick_result_ex": (C.c_int, [c_ctx, P, P, P, P, P, P, P, P]),
     "reloc_tick_accumulate_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, P, C.c_int]),

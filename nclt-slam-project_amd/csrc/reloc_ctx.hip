@@ -256,6 +256,13 @@ RELOC_API int reloc_d2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
     return RELOC_OK;
 }
 
+RELOC_API int reloc_set_exclusive(reloc_ctx *c, int on)
+{
+    ARG_CHECK_CTX(c, true, "ctx is NULL");
+    c->exclusive = on != 0;
+    return RELOC_OK;
+}
+
 RELOC_API void *reloc_host_alloc(int64_t bytes)
 {
     void *p = nullptr;

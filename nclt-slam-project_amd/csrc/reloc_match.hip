@@ -741,6 +741,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 6;
         quota = (n_ids_max + resident * gens - 1) / (resident * gens);    // records per workgroup
         grid = (n_ids_max + quota - 1) / quota;                           // grid x quota >= records: every ticket is served
+        if (ctx->exclusive && ctx->scan_gens == 0) { quota = 0; grid = ctx->num_cu * 4; }     // reloc_set_exclusive: one generation, nobody to hand slots to
         if (ctx->scan_gens < 0) { quota = 0; grid = ctx->num_cu * (ctx->scan_gens <= -2 ? -ctx->scan_gens - 1 : 4); }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
     }
     if (grid > n_ids_max) grid = n_ids_max;

@@ -551,7 +551,7 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
     emit.q[0] = emit.q[1] = emit.q[2] = 0; emit.q[3] = 1;
     emit.g_pts3d = ctx->db_pts3d; emit.g_xy = ctx->f_xy; emit.g_obj = ctx->p_obj; emit.g_img = ctx->p_img;
     // a tick of local candidates runs no whole-database scan: its emit pass and refinement are sized for latency
-    ctx->latency_shapes = prm.mode == RELOC_TICK_LOCAL;
+    ctx->latency_shapes = prm.mode == RELOC_TICK_LOCAL || ctx->exclusive;
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
                         ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
                         ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit);

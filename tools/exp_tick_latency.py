@@ -16,6 +16,8 @@ def one(lib):
     fd = [e.to_device(f) for f in frames]
     res = e.pinned((96,), np.uint8)
     e.tick_result_to(res)
+    if os.environ.get("EXP_EXCLUSIVE", "1") != "0":
+        e.set_exclusive(True)
     out = dict(lib=os.path.basename(lib))
     for i in range(20):
         e.tick_dev(fd[i % 8], 640, 480, base_poses[i % 8], False, 1, i); e.sync()
