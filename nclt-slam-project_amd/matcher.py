@@ -318,10 +318,14 @@ class FusedLandmarkMatcher:
     LandmarkMatcherCore and the reference node."""
 
     def __init__(self, landmarks, log_csv=None, engine=None, config: MatcherConfig | None = None, seed: int = 0,
-                 return_landmarks=None, swap_flag=None, logger=None):
+                 return_landmarks=None, swap_flag=None, logger=None, exclusive: bool = False):
+        """exclusive: this matcher is the only stream of work on the GPU (the reference's deployment: one node, one camera) --
+        Engine.set_exclusive, kernels sized for the latency of one tick; results do not depend on it."""
         from .engine import Engine
         self.cfg = cfg = config or MatcherConfig()
         self.engine = e = engine or Engine()
+        if exclusive:
+            e.set_exclusive(True)
         self.log = logger or (lambda msg: None)
         self.pkl_path = landmarks if isinstance(landmarks, str) else None
         data = load_landmarks(landmarks) if isinstance(landmarks, str) else landmarks

@@ -76,7 +76,8 @@ def make_matcher_node(pkl_path, log_csv, return_pkl=None, swap_flag=None, global
             cfg = MatcherConfig(global_reloc=global_reloc)
             if fused:
                 self.core = FusedLandmarkMatcher(pkl_path, log_csv, config=cfg, return_landmarks=return_pkl,
-                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
+                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m),
+                                                 exclusive=True)          # one node, one camera: the only work on the GPU
             else:
                 self.core = LandmarkMatcherCore(pkl_path, log_csv, cv2=cv2, config=cfg, return_landmarks=return_pkl,
                                                 swap_flag=swap_flag, logger=lambda m: self.get_logger().info(m))
