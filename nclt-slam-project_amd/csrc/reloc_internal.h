@@ -47,6 +47,17 @@ constexpr int MAX_CAND = 32;         // PnP candidates per tick (5 local / 25 gl
 constexpr int MAX_HYP = 1024;        // RANSAC hypotheses per candidate (iterationsCount)
 constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps the record index in 20 bits
 
+// Wave issue priority of the tick's small kernels (s_setprio 3; the default, and the scan's, is 0).  With several streams
+// on the chip a SIMD holds four scan waves and a wave or two of some other stream's ORB / ranking / PnP kernel; those
+// kernels are short dependent chains, and at equal priority they get one issue slot in five, so every stream's non-scan
+// phase stretches 2-3x (k_pyramid 49 vs 17 us, k_fast_blur 46 vs 16) and the scans of the streams overlap less.  With
+// priority the same instructions are issued, only sooner: 4-stream run 6060 -> 6250 frames/s, single-stream ticks unchanged.
+// -DRELOC_SMALL_PRIO=0 switches it off (A/B builds).
+#ifndef RELOC_SMALL_PRIO
+#define RELOC_SMALL_PRIO 3
+#endif
+#define RELOC_SMALL_KERNEL_PRIO() __builtin_amdgcn_s_setprio(RELOC_SMALL_PRIO)
+
 struct OrbLevel {
     int w, h;          // level size
     int stride;        // row stride in bytes (multiple of 64)

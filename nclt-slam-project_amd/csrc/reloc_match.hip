@@ -482,6 +482,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void k_db_scan(
     int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota)
 {
     extern __shared__ u32 lds[];
+    if constexpr (EMIT) RELOC_SMALL_KERNEL_PRIO();          // the emit pass of a few candidates is one of the tick's small kernels
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
     db_scan_body<NJ, EMIT, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
                                emit_stride, mask, ticket, quota);

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__
                                                  int sstride, int order_rgb, uint8_t *__restrict__ pyr, PyrLds lds,
                                                  int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     extern __shared__ u32 s_pyr[];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void k_fast_blur(const OrbTable *__restrict__ 
                                                    uint8_t *__restrict__ nms, int32_t *__restrict__ hist,
                                                    uint8_t *__restrict__ blur, int n_fast)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     if ((int)blockIdx.x < n_fast) fast_nms_tile(tab, pyr, nms, hist, (int)blockIdx.x);
     else blur7_tile(tab, pyr, blur, (int)blockIdx.x - n_fast);
 }
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
                                                 int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
                                                 float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ int s_cut;
     __shared__ int s_n, s_base;
     __shared__ u32 s_list[HARRIS_CHUNK];
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(1024) void k_select(const OrbTable *__restrict__ ta
                                                  int32_t *__restrict__ kp_cnt, u32 *__restrict__ kp_key,
                                                  float *__restrict__ kp_resp)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ u32 s_key[RELOC_ORB_STAGE1_CAP];
     __shared__ float s_resp[RELOC_ORB_STAGE1_CAP];
     __shared__ u32 s_kidx[RELOC_ORB_STAGE1_CAP];
@@ -755,6 +759,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ t
                                                   int32_t *__restrict__ f_oct, uint8_t *__restrict__ f_desc,
                                                   int32_t *__restrict__ f_count)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     int base[NLEV + 1];

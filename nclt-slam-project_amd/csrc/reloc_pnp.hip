@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, c
                                                 const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                 PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
     const int h = blockIdx.x * 64 + threadIdx.x;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(64) void k_pnp_score(const float *__restrict__ obj,
                                                   PnpParams prm, const double *__restrict__ Rt_in,
                                                   int32_t *__restrict__ cnt, uint8_t *__restrict__ mask, int hyp_stride)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
     const int h = blockIdx.x;
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
                                                    const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
                                                    PnpOut *__restrict__ out)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     const int c = blockIdx.x;
     if (n_cand_p && c >= *n_cand_p) return;
     const int lane = threadIdx.x;

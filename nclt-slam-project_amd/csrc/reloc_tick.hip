@@ -236,6 +236,7 @@ __global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t
                                                                    int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n,
                                                                    const int32_t *skip_if, int32_t *__restrict__ relocating)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     extern __shared__ int s_hist[];                     // max_count + 2 bins
     __shared__ int s_wave[16];
     __shared__ int s_cstar, s_above, s_nlist;
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_near(const double *__
                                                                 int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n,
                                                                 int32_t *__restrict__ relocating)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     __shared__ unsigned long long s_near[NEAR_CAP];
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
                                                       const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
                                                       TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     // res: the device record (read by the accumulation and by device-side consumers); res_host: the ctx's own record in
     // pinned host memory, what reloc_tick_result() reads after the stream has drained -- the kernel writes it over PCIe
     // itself, which takes a 5 us copy kernel (and its launch) out of every synchronous tick; res_ext: a caller-named pinned
