@@ -727,10 +727,13 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     // generation of workgroups).  But one generation that lives as long as the launch starves the other streams of a
     // multi-context run: their small kernels get no CU until the scan drains (bench.py, 4 streams: 4800 frames/s against
     // 5050 with r1's static 16-workgroups-per-CU grid, same box).  So a workgroup serves a QUOTA of records and leaves:
-    // the grid holds 6 generations and the deal is still dynamic -- 5110-5200 frames/s in the same runs (2 / 3 / 4 / 6 / 8 /
-    // 12 / 16 generations: 4890 / 4890 / 5030 / 5160 / 5100 / 4960 / 5090; profiles/r2_scan_generations.log).  The price is
-    // the descriptor prologue once per workgroup: the scan alone takes 175 instead of 170 us (RELOC_SCAN_GENS=-1 = one
-    // generation, the fastest form for a single stream).
+    // the grid holds a few generations and the deal is still dynamic -- with 6 generations 5110-5200 frames/s in the same runs
+    // (2 / 3 / 4 / 6 / 8 / 12 / 16 generations: 4890 / 4890 / 5030 / 5160 / 5100 / 4960 / 5090; profiles/r2_scan_generations.log).
+    // The price is the descriptor prologue once per workgroup: the scan alone takes 175 instead of 170 us (RELOC_SCAN_GENS=-1 =
+    // one generation, the fastest form for a single stream; reloc_set_exclusive selects it).
+    // Since the small kernels run at wave priority 3 (RELOC_SMALL_KERNEL_PRIO) they need fewer free slots to keep up, and
+    // THREE generations are the optimum: 2 / 3 / 4 / 6 / 8 / 12: 6535 / 6555 / 6390 / 6260 / 6265 / 5890 frames/s, one
+    // generation 5890 (profiles/r2_scan_generations_prio.log).
     // The short records of the 128-column kernel do not cover the draw latency (Q <= 32: 66 vs 55 us): static there, as
     // for candidate lists and single records.
     const int resident = ctx->num_cu * 4;          // 4 workgroups of 4 waves per CU (128-VGPR kernel)
@@ -739,7 +742,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     int quota = 0;
     if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0 && nj == 8) {
         ticket = ctx->scan_ticket;
-        const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 6;
+        const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 3;
         quota = (n_ids_max + resident * gens - 1) / (resident * gens);    // records per workgroup
         grid = (n_ids_max + quota - 1) / quota;                           // grid x quota >= records: every ticket is served
         if (ctx->exclusive && ctx->scan_gens == 0) { quota = 0; grid = ctx->num_cu * 4; }     // reloc_set_exclusive: one generation, nobody to hand slots to
@@ -790,7 +793,7 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     // n_cur_max = the feature capacity; the 8-column kernel walks column blocks of 512 (one block for nfeatures <= 512)
     const int ncb = (c0->max_feat + 511) / 512;
     const size_t lds_all = (size_t)(ncb * 512 + max_rows + 16) * 4;
-    const int resident = c0->num_cu * 4, gens = c0->scan_gens > 0 ? c0->scan_gens : 6;
+    const int resident = c0->num_cu * 4, gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
     // the grid holds `gens` generations in all (not per frame): a workgroup's quota grows with the batch, and with it
     // the share of the launch that is not prologue
     int per_frame = (resident * gens + n - 1) / n;
