@@ -287,6 +287,7 @@ struct reloc_ctx {
     int32_t *p_inl = nullptr;        // MAX_CAND x MAX_REC_ROWS
     PnpOut *p_out = nullptr;         // MAX_CAND
     bool exclusive = false;          // reloc_set_exclusive: this ctx is the only stream of work on the GPU
+    bool orb_latency_shape = true;   // k_pyramid with 512-thread workgroups; cleared by ticks that share the chip with scans
     bool latency_shapes = false;     // set around the emit pass / PnP of a tick that runs NO whole-database scan (and by the
                                      // single-call entry points): kernels sized for latency instead of for fitting beside a scan
     bool local_two_stage = false;    // developer switch RELOC_LOCAL_TWO_STAGE=1: local candidates by k_topk_part + k_candidates_local

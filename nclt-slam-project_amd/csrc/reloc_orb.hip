@@ -161,10 +161,10 @@ __device__ __forceinline__ void pyr_tab_index(const OrbTable *__restrict__ tab, 
 // q / d for the small quad counts of a tile (q < 2^16, d <= 2^8): exact through one float multiply
 __device__ __forceinline__ int pyr_div(int q, float inv) { return (int)(((float)q + 0.5f) * inv); }
 
-#ifndef PYR_BS
-#define PYR_BS 512
-#endif
-template <int CH, bool ALIGNED>
+// PYR_BS = threads per workgroup: 512 is the fastest alone (256 / 512 / 1024: ORB stage 73 / 68 / 66 us), 256 the best
+// neighbour of a scan (a 256-thread workgroup fits into the slot one retiring scan workgroup frees: 4-stream run 6550 ->
+// 6685 frames/s, synchronous tick +6 us), so both exist: see orb_run_dev.
+template <int CH, bool ALIGNED, int PYR_BS>
 __global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,
                                                  const int32_t *__restrict__ rz, const uint8_t *__restrict__ src, int w, int h,
                                                  int sstride, int order_rgb, uint8_t *__restrict__ pyr, PyrLds lds,
@@ -976,12 +976,16 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
     reloc_prof_begin(ctx, RELOC_PROF_ORB);
     {
         const bool aligned = (w % 4 == 0) && (stride % 4 == 0) && (((uintptr_t)src_dev) % 4 == 0);
-        auto kern = channels == 3 ? (aligned ? k_pyramid<3, true> : k_pyramid<3, false>) : (aligned ? k_pyramid<1, true> : k_pyramid<1, false>);
+        // 512-thread workgroups where nothing scans beside the tick (local-candidate ticks, exclusive contexts, single calls),
+        // 256 in ticks that share the chip with whole-database scans
+        const bool wide = ctx->orb_latency_shape;
+        auto kern512 = channels == 3 ? (aligned ? k_pyramid<3, true, 512> : k_pyramid<3, false, 512>) : (aligned ? k_pyramid<1, true, 512> : k_pyramid<1, false, 512>);
+        auto kern256 = channels == 3 ? (aligned ? k_pyramid<3, true, 256> : k_pyramid<3, false, 256>) : (aligned ? k_pyramid<1, true, 256> : k_pyramid<1, false, 256>);
         PyrLds lds;
         for (int l = 0; l < NLEV; ++l) lds.lev[l] = ctx->pyr_lds[l];
         lds.tabs = ctx->pyr_lds[NLEV];
-        hipLaunchKernelGGL(kern, dim3(ctx->pyr_ntiles), dim3(PYR_BS), ctx->pyr_lds_bytes, st, tab_d, (const PyrTile *)ctx->pyr_tiles,
-                           ctx->rz_tab, src_dev, w, h, stride, order, ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
+        hipLaunchKernelGGL(wide ? kern512 : kern256, dim3(ctx->pyr_ntiles), dim3(wide ? 512 : 256), ctx->pyr_lds_bytes, st, tab_d,
+                           (const PyrTile *)ctx->pyr_tiles, ctx->rz_tab, src_dev, w, h, stride, order, ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
     }
     hipLaunchKernelGGL(k_fast_blur, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr,
                        ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV]);

@@ -582,8 +582,10 @@ RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double 
 //   begin: ORB, local candidates;  scan: whole-database scan (single or batched);  end: ranking, matches, PnP, gates.
 static int tick_begin(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const TickParams &prm)
 {
-    int rc;
-    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
+    ctx->orb_latency_shape = prm.mode == RELOC_TICK_LOCAL || ctx->exclusive;
+    const int rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures);
+    ctx->orb_latency_shape = true;
+    if (rc) return rc;
     if (prm.mode != RELOC_TICK_GLOBAL) launch_candidates_local(ctx, prm);
     return RELOC_OK;
 }
@@ -722,7 +724,10 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
               "reloc_tick_scan_dev");
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
-    if ((rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures))) return rc;
+    ctx->orb_latency_shape = ctx->exclusive;                // the sharded tick scans: a neighbour of scans unless the ctx is alone
+    rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures);
+    ctx->orb_latency_shape = true;
+    if (rc) return rc;
     ScanMask mask;
     mask.xyh = base_pose ? ctx->db_xy_heading : nullptr;
     for (int k = 0; k < 4; ++k) mask.q[k] = base_pose ? base_pose[3 + k] : (k == 3 ? 1.0 : 0.0);
