@@ -42,6 +42,7 @@ __global__ __launch_bounds__(1024) void k_record(const float *__restrict__ f_xy,
                                                  float *__restrict__ o_pts, int32_t *__restrict__ o_idx,
                                                  int32_t *__restrict__ o_n)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ int s_wsum[16];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(1024) void k_accumulate(const float *__restrict__ f
                                                      float *__restrict__ db_kp2d, int64_t *__restrict__ db_off,
                                                      double *__restrict__ db_pose, AccumResult *__restrict__ res)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ int s_wsum[16];
     __shared__ double s_wmin[16];
     __shared__ int s_base;

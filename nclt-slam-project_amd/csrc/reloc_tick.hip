@@ -174,6 +174,7 @@ struct PartKey {
 template <typename KeyFn>
 __global__ __launch_bounds__(TICK_BLOCK) void k_topk_part(KeyFn keyfn, int L, int k, unsigned long long *__restrict__ part)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int begin = blockIdx.x * TOPK_SLICE, end = min(L, begin + TOPK_SLICE);
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *_
                                                                  int32_t *__restrict__ cand_ids, int32_t *__restrict__ cand_n,
                                                                  int32_t *__restrict__ relocating)
 {
+    RELOC_SMALL_KERNEL_PRIO();
     __shared__ unsigned long long s_red[TICK_WAVES * TOPK_MAX];
     __shared__ unsigned long long s_keys[TOPK_MAX + 1];
     const int L = prm.n_records;
