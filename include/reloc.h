@@ -257,11 +257,12 @@ const void *reloc_tick_result_dev(reloc_ctx *ctx);
  * is complete once the ctx stream has passed that tick (event / reloc_sync).  Point it at a different record before each
  * tick to keep one per frame; NULL stops it.  (reloc_tick_result() reads an internal record of the same kind.) */
 int reloc_tick_result_to(reloc_ctx *ctx, void *pinned_record);
-/* Deployment hint, no effect on results: `on` != 0 says this context is the only stream of work on the GPU (one robot,
+/* Deployment hint, no effect on results: `on` > 0 says this context is the only stream of work on the GPU (one robot,
  * one camera).  The whole-database scan then runs as ONE resident generation of workgroups (no early hand-over of CU
  * slots to other streams' kernels) and the tick's small kernels take the shapes that are fastest alone (8 waves per
  * record in the emit pass, full register set in the PnP refinement): ~12 us less per synchronous global tick, at the
- * price of ~10 % throughput if several such contexts do run side by side.  Default 0. */
+ * price of ~10 % throughput if several such contexts do run side by side.  `on` == 0: it is not alone.  `on` < 0 (the
+ * default): decided per call -- alone while it is the only live context this process has created with reloc_create. */
 int reloc_set_exclusive(reloc_ctx *ctx, int on);
 /* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344). */
 int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,

@@ -89,6 +89,8 @@ static int ctx_alloc(reloc_ctx *c)
     return rc;
 }
 
+int g_reloc_live_contexts = 0;
+
 RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat)
 {
     int n = 0;
@@ -106,6 +108,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
         return nullptr;
     }
     reloc_ctx *c = new reloc_ctx();
+    __atomic_add_fetch(&g_reloc_live_contexts, 1, __ATOMIC_RELAXED);     // reloc_destroy (also the failure paths below) takes it back
     c->device = device;
     c->max_w = max_w;
     c->max_h = max_h;
@@ -115,6 +118,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
         reloc_set_error("stream/event creation failed");
+        __atomic_sub_fetch(&g_reloc_live_contexts, 1, __ATOMIC_RELAXED);
         delete c;
         return nullptr;
     }
@@ -140,6 +144,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
     if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
     if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
+    if (const char *e = getenv("RELOC_SCAN_NW")) c->scan_nw = atoi(e);
     if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
@@ -183,6 +188,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    __atomic_sub_fetch(&g_reloc_live_contexts, 1, __ATOMIC_RELAXED);
     delete c;
 }
 
@@ -259,7 +265,7 @@ RELOC_API int reloc_d2d(reloc_ctx *c, void *dst, const void *src, int64_t bytes)
 RELOC_API int reloc_set_exclusive(reloc_ctx *c, int on)
 {
     ARG_CHECK_CTX(c, true, "ctx is NULL");
-    c->exclusive = on != 0;
+    c->exclusive_hint = on < 0 ? -1 : (on != 0);
     return RELOC_OK;
 }
 

@@ -256,6 +256,7 @@ struct reloc_ctx {
     int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
+    int scan_nw = 0;                 // RELOC_SCAN_NW (developer switch): waves per record of the whole-database scan (1, 2, 4); 0 = by shape
     uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 
     // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----
@@ -286,7 +287,8 @@ struct reloc_ctx {
     int32_t *p_cnt = nullptr;        // MAX_CAND x MAX_HYP
     int32_t *p_inl = nullptr;        // MAX_CAND x MAX_REC_ROWS
     PnpOut *p_out = nullptr;         // MAX_CAND
-    bool exclusive = false;          // reloc_set_exclusive: this ctx is the only stream of work on the GPU
+    int exclusive_hint = -1;         // reloc_set_exclusive: 1 = this ctx is the only stream of work on the GPU, 0 = it is not,
+                                     // -1 (default) = it is while it is the only live context of this process (ctx_alone())
     bool orb_latency_shape = true;   // k_pyramid with 512-thread workgroups; cleared by ticks that share the chip with scans
     bool latency_shapes = false;     // set around the emit pass / PnP of a tick that runs NO whole-database scan (and by the
                                      // single-call entry points): kernels sized for latency instead of for fitting beside a scan
@@ -303,6 +305,12 @@ void reloc_prof_end(reloc_ctx *ctx, int which);
 // launchers shared between translation units
 // rec_ids == NULL: scan records 0..n_ids_max-1 and write counts[record]; otherwise scan the listed
 // records (count read from n_ids_dev when non-NULL) and write slot-indexed outputs.
+extern int g_reloc_live_contexts;           // contexts created and not yet destroyed in this process (reloc_ctx.hip)
+static inline bool ctx_alone(const reloc_ctx *c)
+{
+    return c->exclusive_hint > 0 || (c->exclusive_hint < 0 && __atomic_load_n(&g_reloc_live_contexts, __ATOMIC_RELAXED) == 1);
+}
+
 int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off, int64_t n_rec,
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,

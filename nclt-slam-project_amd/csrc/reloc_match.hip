@@ -182,13 +182,14 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // One R-row chunk (R = 16 or 4) of a record against the wave's 64*NJ columns.
 //   q[j]    : descriptor of column colbase + j*64 + lane (padding columns repeat the last real column:
 //             a duplicate offers the same distance with a larger index, so it never wins a minimum)
-//   CLAMP   : tail chunk, row indices clamped to the record's last row (same argument)
+//   FLEX    : tail chunk of nr < R rows: the rows it does not have are skipped (wave-uniform branch) and enter the
+//             butterfly as "infinity"; their fetch addresses are clamped to the record's last row
 // One 16-bit key per pair serves both directions: distance << 7 | row-in-chunk << 3 | column slot.
 // Among the rows of one column the slot bits are equal, so the minimum is (distance, row); among the
 // columns of one row the row bits are equal, so the minimum is (distance, slot).  Per pair that is
 // shift + or + 2 min on top of the 16 instructions of the distance.
-template <int NJ, int R, bool CLAMP>
-__device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, const u32 (&q)[NJ][8],
+template <int NJ, int R, bool FLEX>
+__device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, int nr, const u32 (&q)[NJ][8],
                                            u32 colbase, u32 *rowkey, u32 *colbest, bool single_cb, int lane)
 {
     u32 cb16[NJ];
@@ -203,7 +204,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     u32 stk[LOG_R + 1];
     // Teach rows come through the scalar cache, one fetch in flight (see srow_landed).
     auto bitrev = [](int i) { int r = 0; for (int b = 0; b < LOG_R; ++b) r |= ((i >> b) & 1) << (LOG_R - 1 - b); return r; };
-    auto row_of = [&](int i) { const int t = bitrev(i); return CLAMP ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
+    auto row_of = [&](int i) { const int t = bitrev(i); return FLEX ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
     uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
     // compile-time row and column indices: the key constants are immediates.
     // (Measured and dropped: row i-1's bookkeeping software-pipelined INTO row i's distance chains, one 16-bit instruction
@@ -217,8 +218,8 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         uint4 na, nb;
         if (i + 1 < R) { na = rec[2 * row_of(i + 1)]; nb = rec[2 * row_of(i + 1) + 1]; }   // ... the next one on its way
         __builtin_amdgcn_sched_barrier(0);
-        u32 best = 0;
-        {
+        u32 best = 0x7FFFFFu;                                         // a row the chunk does not have: loses every minimum
+        if (!FLEX || t < nr) {                                           // wave-uniform
             const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             u32 h[NJ];
             ham8_cols<NJ>(q, w, h);                                    // NJ accumulator chains, order pinned
@@ -262,7 +263,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         m = umin(r32[0], r32[1]);
     }
     const int row = tc + (lane & (R - 1));
-    if (lane < R && row < n) {
+    if (lane < (FLEX ? nr : R)) {
         const u32 key = (m & 0xFFFF0000u) | (colbase + ((m >> 9) & 7u) * 64u + (m & 63u));   // distance << 16 | column
         if (single_cb) rowkey[row] = key;
         else atomicMin(&rowkey[row], key);
@@ -320,7 +321,7 @@ __device__ __forceinline__ void db_scan_body(
             q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
         }
     };
-    static_assert(NW == 4 || NW == 8, "wsum[8] is the ticket slot");
+    static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8, "wsum[8] is the ticket slot");
     const bool bound = (NW % ncb) == 0;           // ncb divides the wave count: static wave -> column block binding
     const int my_cb = bound ? wave % ncb : 0;
     const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? NW / ncb : NW;
@@ -400,22 +401,19 @@ __device__ __forceinline__ void db_scan_body(
         if (n > 0 && C > 0) {
             for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
                 if (!bound) load_q(cb * CB);
-                // The record's rows are dealt to the waves bound to this column block as contiguous ranges,
-                // balanced in units of 4 rows; a wave walks its range in 16-row chunks and finishes it in 4-row
-                // chunks (n = 64: one 16-row chunk each; n = 100: 28/24/24/24 rows instead of 32/32/32/4).  A tail
-                // chunk may run past the range: rows that belong to the next wave are simply computed twice (all
-                // merges are idempotent minima), rows past the record are clamped.
-                const int units = (n + 3) >> 2, per = units / chunk_step, extra = units % chunk_step;
-                int tc = (chunk0 * per + min(chunk0, extra)) * 4;
-                const int tend = min(n, tc + (per + (chunk0 < extra ? 1 : 0)) * 4);
-                for (; tend - tc >= 16; tc += 16)
-                    scan_chunk<NJ, 16, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                for (; tc < tend; tc += 4) {
-                    if (tc + 4 <= n)
-                        scan_chunk<NJ, 4, false>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                    else
-                        scan_chunk<NJ, 4, true>(rec, n, tc, q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
-                }
+                // The record's rows are dealt to the waves bound to this column block as contiguous ranges, balanced to
+                // the single row; a wave walks its range in 16-row chunks and finishes it with ONE flexible chunk of
+                // 1-15 rows (n = 64, 4 waves: one 16-row chunk each; n = 45: 12/11/11/11 rows = one flexible chunk each
+                // -- round 2 walked tails in 4-row chunks and paid the chunk epilogue, butterfly + 9 LDS minima, every 4
+                // rows: 1.56 T pairs/s on 45-row records against 2.0 T on 64-row ones).
+                const int per = n / chunk_step, extra = n % chunk_step;
+                int tc = chunk0 * per + min(chunk0, extra);
+                const int tend = tc + per + (chunk0 < extra ? 1 : 0);
+                // ONE instantiation serves full and partial chunks: the unrolled 16-row body is 45 KB of code, two of them
+                // would not share the 64 KB instruction cache
+#pragma nounroll
+                for (; tc < tend; tc += 16)
+                    scan_chunk<NJ, 16, true>(rec, n, tc, min(16, tend - tc), q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
             }
         }
         __syncthreads();
@@ -468,13 +466,148 @@ __device__ __forceinline__ void db_scan_body(
     }
 }
 
+// The counting scan (no match lists): the per-record flow of db_scan_body reduced to TWO barriers per record.
+//   - colbest is double-buffered: the buffer of the NEXT record is cleared while this record's chunks run, so no
+//     clear / barrier pair stands in front of a record;
+//   - with one column block (<= 64 * NJ current descriptors: every fused tick) each row key is written by exactly one
+//     wave with a plain store and never needs clearing;
+//   - the mutual pairs are only counted: per wave one ballot and one LDS add, no prefix sums;
+//   - the next record's ticket (drawn a record ahead) is settled between the same two barriers.
+// A workgroup's FIRST record is dealt statically (record = workgroup index, no counter round trip in front of the first
+// row); the counters deal the records behind the grid.  Round 2's flow had six barriers per record and waited for an
+// atomic before the first row: 10 000 x 64 in three generations 162 -> [see DESIGN.md] us.
+template <int NJ, int NW>
+__device__ __forceinline__ void db_count_body(
+    u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
+    const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
+    int32_t *__restrict__ counts, const ScanMask &mask, u32 *ticket, int quota, u32 *ticket_pool = nullptr,
+    int pool_frames = 1, int block = -1, int n_blocks = -1)
+{
+    if (!ticket_pool) ticket_pool = ticket;
+    if (block < 0) { block = blockIdx.x; n_blocks = gridDim.x; }
+    constexpr int CB = 64 * NJ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_ids = n_ids_p ? min(*n_ids_p, n_ids_max) : n_ids_max;
+    const int ncb = max((C + CB - 1) / CB, 1);
+    u32 *colbuf = lds;                        // 2 x ncb * CB : best (distance << 16 | row) per column, double-buffered
+    u32 *rowkey = colbuf + 2 * ncb * CB;      // max_rows     : best (distance << 16 | column) per row
+    u32 *wsum = rowkey + max_rows;            // [0], [1]: mutual-pair counters of the two buffers; [8]: next record
+
+    u32 q[NJ][8];
+    auto load_q = [&](int colbase) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = min(colbase + j * 64 + lane, max(C - 1, 0));   // padding repeats the last column
+            const uint4 a = cur[2 * col], b = cur[2 * col + 1];
+            q[j][0] = a.x; q[j][1] = a.y; q[j][2] = a.z; q[j][3] = a.w;
+            q[j][4] = b.x; q[j][5] = b.y; q[j][6] = b.z; q[j][7] = b.w;
+        }
+    };
+    const bool bound = (NW % ncb) == 0;
+    const int my_cb = bound ? wave % ncb : 0;
+    const int chunk0 = bound ? wave / ncb : wave, chunk_step = bound ? NW / ncb : NW;
+    const bool stand_down = mask.skip_if && *mask.skip_if != 0;
+    if (bound && !stand_down) load_q(my_cb * CB);
+    double hc = 1.0, hs = 0.0, cos_tol = 0.0;
+    if (mask.xyh) {
+        cur_heading_q(mask.q, hc, hs);
+        cos_tol = mask.cos_tol;
+    }
+    constexpr int TICKET_STRIDE = 32;
+    int shard = 0, dry = 0;
+    if (ticket) {
+        u32 x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+        shard = (int)(x & 7u);
+    }
+    auto draw = [&]() -> u32 { return atomicAdd(&ticket[shard * TICKET_STRIDE], 1u); };
+    // thread 0: ticket -> record index; counter x deals records n_blocks + x, n_blocks + x + 8, ... (the first n_blocks
+    // records are the workgroups' static first records)
+    auto settle = [&](u32 t) -> int {
+        for (;;) {
+            const long long rec_i = (long long)n_blocks + (long long)shard + 8ll * (long long)t;
+            if (rec_i < n_ids) return (int)rec_i;
+            if (++dry >= 8) return n_ids;
+            shard = (shard + 1) & 7;
+            t = draw();
+        }
+    };
+    int it = stand_down ? n_ids : block;
+    int left = quota > 0 ? quota : 0x7fffffff;
+    for (int i = tid; i < ncb * CB; i += 64 * NW) colbuf[i] = 0xFFFFFFFFu;
+    if (tid == 0) wsum[0] = wsum[1] = 0;
+    __syncthreads();
+    int p = 0;
+    while (it < n_ids) {
+        --left;
+        u32 next_ticket = 0;
+        if (ticket && tid == 0 && left > 0) next_ticket = draw();        // no draw that this workgroup would not serve
+        u32 *colbest = colbuf + p * ncb * CB;
+        const int r = rec_ids ? rec_ids[it] : it;
+        const bool scored = !(mask.xyh && !heading_ok(mask.xyh + 4 * (int64_t)r, hc, hs, cos_tol));      // workgroup-uniform
+        const int64_t row0 = off[r];
+        const int n = scored ? (int)(off[r + 1] - row0) : 0;
+        const uint4 *rec = db + 2 * row0;
+        if (n > 0 && C > 0) {
+            if (ncb > 1) {                                               // several waves write one row's key: atomic minima
+                for (int i = tid; i < n; i += 64 * NW) rowkey[i] = 0xFFFFFFFFu;
+                __syncthreads();
+            }
+            for (int cb = bound ? my_cb : 0; cb < (bound ? my_cb + 1 : ncb); ++cb) {
+                if (!bound) load_q(cb * CB);
+                // rows dealt to the waves of this column block as contiguous ranges balanced to the single row; 16-row
+                // chunks, the last one partial (see db_scan_body)
+                const int per = n / chunk_step, extra = n % chunk_step;
+                int tc = chunk0 * per + min(chunk0, extra);
+                const int tend = tc + per + (chunk0 < extra ? 1 : 0);
+#pragma nounroll
+                for (; tc < tend; tc += 16)
+                    scan_chunk<NJ, 16, true>(rec, n, tc, min(16, tend - tc), q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
+            }
+        }
+        {   // the other buffer, for the next record
+            u32 *other = colbuf + (p ^ 1) * ncb * CB;
+            for (int i = tid; i < ncb * CB; i += 64 * NW) other[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();                                                  // every minimum of this record is in LDS
+        if (C > 0) {
+            for (int rb = 0; rb < n; rb += 64 * NW) {                     // wave-uniform trip count
+                const int row = rb + tid;
+                bool mutual = false;
+                if (row < n) {
+                    const u32 col = rowkey[row] & 0xFFFFu;
+                    mutual = (colbest[col] & 0xFFFFu) == (u32)row;
+                }
+                const u32 c = (u32)__popcll(__ballot(mutual));
+                if (lane == 0 && c) atomicAdd(&wsum[p], c);
+            }
+        }
+        if (tid == 0) wsum[8] = ticket ? (left > 0 ? (u32)settle(next_ticket) : (u32)n_ids) : (u32)(it + n_blocks);
+        __syncthreads();
+        if (tid == 0) {
+            counts[r] = (int32_t)wsum[p];
+            wsum[p] = 0;
+        }
+        it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
+        p ^= 1;
+    }
+    if (ticket && tid == 0) {
+        const int words = pool_frames * 8;
+        if (atomicAdd(&ticket_pool[words * TICKET_STRIDE], 1u) == gridDim.x - 1) {      // every other workgroup has made its last draw
+            for (int x = 0; x <= words; ++x)
+                __hip_atomic_store(&ticket_pool[x * TICKET_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // The kernel proper.  NJ is chosen by the host from the CAPACITY of the current-descriptor buffer: entry points
 // that know the query count (reloc_db_match_counts*, reloc_match_mutual) scan 128 or 256 columns per wave when
 // that is enough, so their cost follows the query count instead of being flat below 512; the fused tick passes
 // its feature capacity and always runs NJ = 8.  (One kernel branching on the device-side count was measured:
 // it costs the NJ = 8 path 3 %.)
 template <int NJ, bool EMIT, int NW>
-__global__ __launch_bounds__(64 * NW, 16 / NW) void k_db_scan(
+__global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
     const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
@@ -484,8 +617,11 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void k_db_scan(
     extern __shared__ u32 lds[];
     if constexpr (EMIT) RELOC_SMALL_KERNEL_PRIO();          // the emit pass of a few candidates is one of the tick's small kernels
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
-    db_scan_body<NJ, EMIT, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
-                               emit_stride, mask, ticket, quota);
+    if constexpr (EMIT)
+        db_scan_body<NJ, true, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
+                                   emit_stride, mask, ticket, quota);
+    else
+        db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota);
 }
 
 // Several frames in ONE launch (BASELINE.json config 4: batched relocalization): workgroup b scans frame b % B -- its
@@ -515,9 +651,8 @@ __global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restric
     mask.cos_tol = bt.cos_tol;
     mask.skip_if = bt.skip_if[f];
     const int C = bt.n_cur[f] ? min(*bt.n_cur[f], n_cur_max) : n_cur_max;
-    db_scan_body<8, false>(lds, C, db, off, nullptr, nullptr, n_ids, bt.cur[f], max_rows, bt.counts[f], nullptr, nullptr, nullptr,
-                           nullptr, 0, mask, ticket_pool + f * 8 * 32, quota, ticket_pool, bt.n, (int)(blockIdx.x / bt.n),
-                           (int)((gridDim.x + bt.n - 1 - f) / bt.n));
+    db_count_body<8, 4>(lds, C, db, off, nullptr, nullptr, n_ids, bt.cur[f], max_rows, bt.counts[f], mask, ticket_pool + f * 8 * 32, quota,
+                        ticket_pool, bt.n, (int)(blockIdx.x / bt.n), (int)((gridDim.x + bt.n - 1 - f) / bt.n));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -719,7 +854,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int nj = n_cur_max <= 128 ? 2 : (n_cur_max <= 256 ? 4 : 8);      // columns per lane, see k_db_scan
     const int cb = 64 * nj;
     const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;
-    const size_t lds = (size_t)(ncb * cb + max_rows + 16) * 4;
+    const size_t lds = (size_t)((m_qidx ? 1 : 2) * ncb * cb + max_rows + 16) * 4;     // the counting scan double-buffers its column minima
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
     // Whole-database scans (host-known record count, more records than resident workgroups): workgroups DRAW their records
     // from per-XCD ticket counters instead of a static round-robin deal, so the work stays balanced to the last record
@@ -736,7 +871,14 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     // generation 5890 (profiles/r2_scan_generations_prio.log).
     // The short records of the 128-column kernel do not cover the draw latency (Q <= 32: 66 vs 55 us): static there, as
     // for candidate lists and single records.
-    const int resident = ctx->num_cu * 4;          // 4 workgroups of 4 waves per CU (128-VGPR kernel)
+    // Waves per record of the counting scan (NW): 4 waves share a record's rows (finest grain: shortest tail of the launch),
+    // or 2, or ONE wave owns a record (no row left for a second chunk epilogue, no barrier that waits for anybody).
+    int nw = 4;
+    if (!m_qidx && nj == 8) {
+        nw = ctx->scan_nw == 1 || ctx->scan_nw == 2 || ctx->scan_nw == 4 ? ctx->scan_nw : 4;
+        if (nw == 1 && lds * 16 > 150 * 1024) nw = 2;          // 16 one-wave workgroups per CU have to fit their LDS
+    }
+    const int resident = ctx->num_cu * 16 / nw;    // 16 waves per CU (128-VGPR kernel)
     int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
     u32 *ticket = nullptr;
     int quota = 0;
@@ -745,8 +887,8 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 3;
         quota = (n_ids_max + resident * gens - 1) / (resident * gens);    // records per workgroup
         grid = (n_ids_max + quota - 1) / quota;                           // grid x quota >= records: every ticket is served
-        if (ctx->exclusive && ctx->scan_gens == 0) { quota = 0; grid = ctx->num_cu * 4; }     // reloc_set_exclusive: one generation, nobody to hand slots to
-        if (ctx->scan_gens < 0) { quota = 0; grid = ctx->num_cu * (ctx->scan_gens <= -2 ? -ctx->scan_gens - 1 : 4); }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
+        if (ctx_alone(ctx) && ctx->scan_gens == 0) { quota = 0; grid = resident; }     // reloc_set_exclusive: one generation, nobody to hand slots to
+        if (ctx->scan_gens < 0) { quota = 0; grid = ctx->scan_gens <= -2 ? ctx->num_cu * (-ctx->scan_gens - 1) : resident; }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
     }
     if (grid > n_ids_max) grid = n_ids_max;
     // Match lists of a few candidate records (the tick's emit pass, reloc_match_mutual): one workgroup per record is
@@ -763,8 +905,10 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 8); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 8); else RELOC_LAUNCH_SCAN(8, true, 8);
     } else if (m_qidx) {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 4); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 4); else RELOC_LAUNCH_SCAN(8, true, 4);
+    } else if (nj == 8) {
+        if (nw == 1) RELOC_LAUNCH_SCAN(8, false, 1); else if (nw == 2) RELOC_LAUNCH_SCAN(8, false, 2); else RELOC_LAUNCH_SCAN(8, false, 4);
     } else {
-        if (nj == 2) RELOC_LAUNCH_SCAN(2, false, 4); else if (nj == 4) RELOC_LAUNCH_SCAN(4, false, 4); else RELOC_LAUNCH_SCAN(8, false, 4);
+        if (nj == 2) RELOC_LAUNCH_SCAN(2, false, 4); else RELOC_LAUNCH_SCAN(4, false, 4);
     }
 #undef RELOC_LAUNCH_SCAN
     HIP_TRY(hipGetLastError());
@@ -792,7 +936,7 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     const int n_ids = (int)c0->db_records, max_rows = c0->db_max_rows < 1 ? 1 : c0->db_max_rows;
     // n_cur_max = the feature capacity; the 8-column kernel walks column blocks of 512 (one block for nfeatures <= 512)
     const int ncb = (c0->max_feat + 511) / 512;
-    const size_t lds_all = (size_t)(ncb * 512 + max_rows + 16) * 4;
+    const size_t lds_all = (size_t)(2 * ncb * 512 + max_rows + 16) * 4;
     const int resident = c0->num_cu * 4, gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
     // the grid holds `gens` generations in all (not per frame): a workgroup's quota grows with the batch, and with it
     // the share of the launch that is not prologue

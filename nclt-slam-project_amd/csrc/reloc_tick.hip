@@ -556,7 +556,7 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
     emit.q[0] = emit.q[1] = emit.q[2] = 0; emit.q[3] = 1;
     emit.g_pts3d = ctx->db_pts3d; emit.g_xy = ctx->f_xy; emit.g_obj = ctx->p_obj; emit.g_img = ctx->p_img;
     // a tick of local candidates runs no whole-database scan: its emit pass and refinement are sized for latency
-    ctx->latency_shapes = prm.mode == RELOC_TICK_LOCAL || ctx->exclusive;
+    ctx->latency_shapes = prm.mode == RELOC_TICK_LOCAL || ctx_alone(ctx);
     rc = launch_db_scan(ctx, ctx->db_desc, ctx->db_off, ctx->db_records, ctx->cand_ids, ctx->cand_n, MAX_CAND,
                         ctx->f_desc, ctx->f_count, ctx->max_feat, ctx->db_max_rows, nullptr, ctx->m_qidx, ctx->m_tidx,
                         ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit);
@@ -584,7 +584,7 @@ RELOC_API int reloc_set_camera(reloc_ctx *ctx, const double K4[4], const double 
 //   begin: ORB, local candidates;  scan: whole-database scan (single or batched);  end: ranking, matches, PnP, gates.
 static int tick_begin(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const TickParams &prm)
 {
-    ctx->orb_latency_shape = prm.mode == RELOC_TICK_LOCAL || ctx->exclusive;
+    ctx->orb_latency_shape = prm.mode == RELOC_TICK_LOCAL || ctx_alone(ctx);
     const int rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures);
     ctx->orb_latency_shape = true;
     if (rc) return rc;
@@ -726,7 +726,7 @@ RELOC_API int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w,
               "reloc_tick_scan_dev");
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     int rc;
-    ctx->orb_latency_shape = ctx->exclusive;                // the sharded tick scans: a neighbour of scans unless the ctx is alone
+    ctx->orb_latency_shape = ctx_alone(ctx);                // the sharded tick scans: a neighbour of scans unless the ctx is alone
     rc = orb_run_dev(ctx, img_dev, w, h, w * 3, 3, order, ctx->prm.nfeatures);
     ctx->orb_latency_shape = true;
     if (rc) return rc;

@@ -100,10 +100,10 @@ class Engine:
     def tick_result_dev(self) -> int:
         return int(self._lib.reloc_tick_result_dev(self._ctx))
 
-    def set_exclusive(self, on: bool):
+    def set_exclusive(self, on: bool | None):
         """deployment hint (no effect on results): this context is the only stream of work on the GPU -- kernels sized for
         the latency of one synchronous tick instead of for sharing the chip with other streams (reloc_set_exclusive)"""
-        N.check(self._lib.reloc_set_exclusive(self._ctx, int(bool(on))), "reloc_set_exclusive")
+        N.check(self._lib.reloc_set_exclusive(self._ctx, -1 if on is None else int(bool(on))), "reloc_set_exclusive")
 
     def tick_result_to(self, record: np.ndarray | None):
         """the ticks enqueued from now on also write their 96-byte result record into `record` (a slice of a pinned() array;

@@ -22,29 +22,38 @@ def out(**kw):
 
 
 def scan_cases(e):
+    """Every case in both scheduling forms of the whole-database scan: `shared` = three generations of workgroups with a
+    record quota (what a context runs when other contexts of the process work beside it: bench.py's 4 streams) and
+    `alone` = one resident generation (reloc_set_exclusive, and the default of a process's only context)."""
     rng = np.random.default_rng(5)
-    for rows, L in (("fixed64", 10000), ("ragged", 10000), (45, 10000), (100, 10000), ("fixed64", 100000)):
+    small = (1, 8, 32)
+    for rows, L, Qs in (("fixed64", 10000, small + (500, 4000)), ("ragged", 10000, (500,)), (45, 10000, (500,)), (100, 10000, (500,)),
+                        ("fixed64", 100000, small + (500,)), ("ragged", 100000, small + (500,)), (45, 100000, (500,))):
         desc, pts, off, poses = synth.descriptor_db(rng, L, rows)
         e.db_upload(desc, pts, off, poses)
         T = int(off[-1])
         cnt = e.dev_alloc(L * 4)
-        for Q in ((1, 32, 500, 4000) if rows == "fixed64" and L == 10000 else (500,)):
+        for Q in Qs:
             cur = e.to_device(synth.random_descriptors(rng, Q))
-            for _ in range(3):
-                e.db_match_counts_dev(cur, Q, cnt)
-            e.sync()
-            e.profile_enable(True)
-            n = 20
-            for _ in range(n):
-                e.db_match_counts_dev(cur, Q, cnt)
-            e.sync()
-            ms, k = e.profile_get(PROF_DB_SCAN)
-            e.profile_enable(False)
-            us = ms / k * 1e3
-            alg = 32 * T + 32 * Q + 4 * L
-            out(case="db_scan", rows=str(rows), records=L, descriptors=T, Q=Q, us=round(us, 1),
-                pairs_per_s=T * Q / (us * 1e-6), algorithmic_GBps=alg / (us * 1e-6) / 1e9, hbm_frac=alg / (us * 1e-6) / 8e12,
-                note="lane = teach row kernel (k_db_scan_rows)" if Q <= 64 else "")
+            for alone in ((None,) if Q <= 64 else (False, True)):
+                e.set_exclusive(alone)
+                for _ in range(30):                   # also the clock-settling pre-roll (DESIGN.md section 4)
+                    e.db_match_counts_dev(cur, Q, cnt)
+                e.sync()
+                e.profile_enable(True)
+                n = 40
+                for _ in range(n):
+                    e.db_match_counts_dev(cur, Q, cnt)
+                e.sync()
+                ms, k = e.profile_get(PROF_DB_SCAN)
+                e.profile_enable(False)
+                us = ms / k * 1e3
+                alg = 32 * T + 32 * Q + 4 * L
+                out(case="db_scan", rows=str(rows), records=L, descriptors=T, Q=Q,
+                    scheduling="-" if Q <= 64 else ("alone" if alone else "shared"), us=round(us, 1),
+                    pairs_per_s=T * Q / (us * 1e-6), algorithmic_GBps=alg / (us * 1e-6) / 1e9, hbm_frac=alg / (us * 1e-6) / 8e12,
+                    note="lane = teach row kernel (k_db_scan_rows)" if Q <= 64 else "")
+            e.set_exclusive(None)
             e.dev_free(cur)
         e.dev_free(cnt)
 
