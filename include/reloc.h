@@ -181,8 +181,10 @@ int reloc_db_append(reloc_ctx *ctx, const uint8_t *desc, const float *pts3d, con
 int reloc_db_select(reloc_ctx *ctx, int slot);
 /* Several contexts (streams) on one device scanning ONE resident database: dst adopts the selected database of src
  * (descriptors, points, offsets, poses, index) without copying and keeps only its own per-tick scratch.  The shared
- * database is read-only through dst (upload / append / reserve on dst fail with RELOC_E_STATE); src must outlive dst or
- * dst must upload / share again first, and changes made through src (append, upload) need a new reloc_db_share. */
+ * database is read-only through dst (append / reserve on dst fail with RELOC_E_STATE).  dst sees the database as it was
+ * when it was adopted: records that src appends or accumulates later, and a new upload through src, need a new
+ * reloc_db_share to become visible.  The arrays are reference-counted: src may grow past its reserve, upload again or be
+ * destroyed at any time -- dst keeps scanning the arrays it adopted, which are freed when their last holder lets go. */
 int reloc_db_share(reloc_ctx *dst, reloc_ctx *src);
 /* Read one record back (save of the augmented database M:502-514, parity taps).  Any output may be NULL; desc / pts3d /
  * kp2d must hold the record's rows (query *n first with all arrays NULL). */
@@ -287,6 +289,27 @@ int reloc_tick_scan_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, in
                         int32_t *topk_ids_dev, int32_t *topk_counts_dev, int k);
 int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand,
                          const double base_pose[7], int check_consistency, uint64_t seed);
+/* The same two halves for a BATCH of n <= 8 frames (BASELINE.json config 4) with the exchange kept in device memory: one
+ * call per half, everything enqueued on the ONE stream the n contexts share (as for reloc_tick_batch_dev: one device, one
+ * shard through reloc_db_share, equal capacity and parameters), so the caller's collective (RCCL all-gather of the rows
+ * below) can be enqueued on that same stream between them and the host never waits inside a batch.
+ *   scan half:  ORB per frame, ONE scan launch for the n frames, per-frame ranking.  scan_out_dev: n rows of 2k + 2
+ *               int32 = k GLOBAL record ids (id_base + local id, -1 padded), k mutual-match counts, the frame's feature
+ *               count, 0.  base_poses: n x 7 (heading mask, G:329-330) or NULL.
+ *   merge:      what every rank computes from the gathered rows (all_scan_dev: `world` blocks `stride_rank` int32 apart,
+ *               each n rows as above): per frame the k best (count desc, global id desc; G:342-343) -> win_gid (n x k,
+ *               -1 padded), cand_local (n x k: local ids of the winners THIS rank owns, -1 elsewhere), n_feat (n: the
+ *               largest feature count any rank reported, -1 from ranks without records).
+ *   solve half: match lists + PnP + gates (relocation gates, no consistency check, G:381-382,424) for the owned winners of
+ *               every frame; the 96-byte result record of frame f is stored at res_out + 96 f by the tick's last kernel
+ *               (device or pinned host memory). */
+int reloc_shard_scan_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
+                               const double *base_poses, int k, int64_t id_base, int32_t *scan_out_dev);
+int reloc_shard_merge_dev(reloc_ctx *ctx, const int32_t *all_scan_dev, int world, int64_t stride_rank, int n, int k,
+                          int64_t id_base, int64_t n_local, int32_t *win_gid_dev, int32_t *cand_local_dev,
+                          int32_t *n_feat_dev);
+int reloc_shard_solve_batch_dev(reloc_ctx *const *ctxs, int n, const int32_t *cand_local_dev, int k,
+                                const double *base_poses, const uint64_t *seeds, void *res_out);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,9 @@ SIGNATURES = {
     "reloc_accumulate_result": (C.c_int, [c_ctx, P, P, P]),
     "reloc_tick_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, C.c_int, u64]),
     "reloc_tick_batch_dev": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]),
+    "reloc_shard_scan_batch_dev": (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, C.c_int, P, C.c_int, i64, P]),
+    "reloc_shard_merge_dev": (C.c_int, [c_ctx, P, C.c_int, i64, C.c_int, C.c_int, i64, i64, P, P, P]),
+    "reloc_shard_solve_batch_dev": (C.c_int, [P, C.c_int, P, C.c_int, P, P, P]),
     "reloc_tick_result": (C.c_int, [c_ctx, P, P, P, P, P, P]),
     "reloc_tick_scan_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, P, P, C.c_int]),
     "reloc_tick_solve_dev": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, u64]),
@@ -101,6 +104,27 @@ class RelocError(RuntimeError):
     """Raised for every failure of the native library (the cv2 shim re-raises it as cv2.error)."""
 
 
+def _one_hip_runtime():
+    """A process must run on ONE HIP runtime.  libreloc_hip.so needs `libamdhip64.so.7` and would take /opt/rocm's;
+    PyTorch-ROCm ships its own copy under torch/lib with the same SONAME.  Whichever is mapped first serves both -- and
+    torch on /opt/rocm's runtime reports "No HIP GPUs are available".  So, when torch is installed but not imported yet,
+    its bundled runtime is mapped here first (without importing torch): afterwards the import order of torch and this
+    package does not matter.  Without torch the library uses /opt/rocm's runtime.  RELOC_HIP_RUNTIME=system skips this."""
+    import sys
+    if os.environ.get("RELOC_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):      # no torch, or a CPU-only torch: /opt/rocm's runtime is used
+        pass
+
+
 def load(strict: bool = True):
     """Loads the shared library and binds every symbol of include/reloc.h."""
     global _lib
@@ -110,6 +134,7 @@ def load(strict: bool = True):
         raise RelocError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  There is no CPU fallback.")
+    _one_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

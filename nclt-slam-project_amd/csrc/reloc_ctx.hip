@@ -145,6 +145,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
     if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
     if (const char *e = getenv("RELOC_SCAN_NW")) c->scan_nw = atoi(e);
+    if (const char *e = getenv("RELOC_SCAN_BATCH_GENS")) c->scan_batch_gens = atoi(e);
     if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
@@ -158,24 +159,21 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->db_shared) {       // the arrays belong to another ctx; only the scratch is ours
-        c->db_desc = nullptr; c->db_pts3d = nullptr; c->db_kp2d = nullptr; c->db_off = nullptr; c->db_pose = nullptr;
-        c->db_xy_heading = nullptr;
-    }
+    // database arrays: one reference each (owner or adopter alike); counts / topk_part are this context's own scratch
+    db_arrays_drop(c->db_share, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off, c->db_pose, c->db_xy_heading);
     void *ptrs[] = {c->pyr, c->blur, c->nms, c->rz_tab, c->pyr_tiles, c->hist, c->cand_cnt, c->cand_key, c->cand_resp,
                     c->kp_cnt, c->kp_key, c->kp_resp, c->f_xy, c->f_size, c->f_angle, c->f_resp, c->f_oct,
-                    c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_desc, c->db_pts3d, c->db_kp2d, c->db_off,
-                    c->db_pose, c->db_xy_heading, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,
+                    c->f_desc, c->f_count, c->frame_img, c->orb_const, c->dbg_cut, c->db_counts, c->topk_part, c->cand_ids, c->cand_n, c->m_qidx,
                     c->m_tidx, c->m_dist, c->m_n, c->p_obj, c->p_img, c->p_Rt, c->p_cnt, c->p_inl,
                     c->p_out, c->tick_res, c->accum_res, c->tick_flags, c->scan_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->tick_res_host) (void)hipHostFree(c->tick_res_host);
     {   // the database that is not selected
-        const DbArena &a = c->db_slot[1 - c->db_sel];
-        void *q[] = {a.desc, a.pts3d, a.kp2d, a.off, a.pose, a.xy_heading, a.counts, a.topk_part};
-        for (void *p : q)
-            if (p) (void)hipFree(p);
+        DbArena &a = c->db_slot[1 - c->db_sel];
+        db_arrays_drop(a.share, a.desc, a.pts3d, a.kp2d, a.off, a.pose, a.xy_heading);
+        if (a.counts) (void)hipFree(a.counts);
+        if (a.topk_part) (void)hipFree(a.topk_part);
     }
     for (int i = 0; i < 8; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);

@@ -88,7 +88,15 @@ struct AccumResult {
 };
 
 // One resident landmark database: structure of arrays with reserved capacity (rows: cap_rows, records: cap_records).
+// The six database arrays of one arena (desc, pts3d, kp2d, off, pose, xy_heading) are held by reference count: the
+// context that uploaded them and every context that adopted them with reloc_db_share hold one reference each, and the
+// arrays are freed by whoever lets go last.  An owner that re-allocates (growth past the reserve, a new upload) or is
+// destroyed therefore never frees memory an adopter still scans: the adopter keeps the arrays -- and the record count --
+// it adopted until it calls reloc_db_share / reloc_db_upload again.
+struct DbShare { int refs = 1; };
+
 struct DbArena {
+    DbShare *share = nullptr;
     int64_t cap_records = 0, cap_rows = 0;
     int64_t records = 0, rows = 0;
     int max_rows = 0;
@@ -256,13 +264,15 @@ struct reloc_ctx {
     int scan_grid = 0;               // RELOC_SCAN_GRID (developer switch), read once at creation: > 0 static grid of that
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
+    int scan_batch_gens = 0;         // RELOC_SCAN_BATCH_GENS (developer switch): generations of a batched scan launch
     int scan_nw = 0;                 // RELOC_SCAN_NW (developer switch): waves per record of the whole-database scan (1, 2, 4); 0 = by shape
     uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 
     // ---- database: two arenas, the fields below are the SELECTED one's (reloc_db_select copies them) ----
     DbArena db_slot[2];
     int db_sel = 0;
-    bool db_shared = false;          // the selected database's arrays belong to another ctx (reloc_db_share)
+    bool db_shared = false;          // the selected database's arrays were adopted from another ctx (reloc_db_share): read-only here
+    DbShare *db_share = nullptr;     // reference count of the selected arena's six shared arrays
     int64_t db_records = 0, db_rows = 0;
     int64_t db_cap_records = 0, db_cap_rows = 0;
     int db_max_rows = 0;
@@ -305,6 +315,8 @@ void reloc_prof_end(reloc_ctx *ctx, int which);
 // launchers shared between translation units
 // rec_ids == NULL: scan records 0..n_ids_max-1 and write counts[record]; otherwise scan the listed
 // records (count read from n_ids_dev when non-NULL) and write slot-indexed outputs.
+// lets go of one reference to an arena's six arrays; frees them when it was the last (reloc_match.hip)
+void db_arrays_drop(DbShare *&share, uint8_t *&desc, float *&pts3d, float *&kp2d, int64_t *&off, double *&pose, double *&xyh);
 extern int g_reloc_live_contexts;           // contexts created and not yet destroyed in this process (reloc_ctx.hip)
 static inline bool ctx_alone(const reloc_ctx *c)
 {
@@ -315,12 +327,16 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
                    const int32_t *rec_ids, const int32_t *n_ids_dev, int n_ids_max, const uint8_t *cur,
                    const int32_t *n_cur_dev, int n_cur_max, int max_rows, int32_t *counts, int32_t *m_qidx,
                    int32_t *m_tidx, int32_t *m_dist, int32_t *m_n, int emit_stride, const ScanMask *mask = nullptr);
-int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double cos_tol, bool auto_mode);
+int launch_db_emit_batch(reloc_ctx *const *ctxs, int n);
+int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double cos_tol, bool auto_mode, bool heading_mask = true);
 int db_reindex(reloc_ctx *ctx);
 int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows);
 inline bool db_ready(const reloc_ctx *ctx) { return ctx->db_desc && ctx->db_off && ctx->db_pose && ctx->db_xy_heading && ctx->db_counts && ctx->db_records > 0; }
 int orb_prepare(reloc_ctx *ctx, int w, int h, int nfeatures);
+constexpr int RELOC_BATCH_MAX = 8;          // frames per batched launch (reloc_tick_batch_dev, reloc_shard_*_batch_dev)
+int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_dev, int w, int h, int stride, int order, int nfeatures);
 int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,
                 int nfeatures);
+int pnp_run_candidates_batch(reloc_ctx *const *ctxs, int n, int n_cand_max, const uint64_t *seeds);
 int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4],
                        int iters, float thr_px, double conf, uint64_t seed, int min_m);

@@ -27,6 +27,7 @@
 // order.  Keys are (distance << k | index): the minimum of packed keys is the smallest distance
 // with the LOWEST index on ties, which is the tie rule of the specification.
 #include <stdlib.h>
+#include <new>
 #include <type_traits>
 #include <utility>
 
@@ -624,6 +625,51 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
         db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota);
 }
 
+// The emit pass (match lists of the candidate records, M:327-336) of up to 8 frames in one launch: blockIdx.y = frame.
+struct EmitFrame {
+    const int32_t *rec_ids, *n_ids_p; const uint4 *cur; const int32_t *n_cur_p;
+    int32_t *m_qidx, *m_tidx, *m_dist, *m_n; const float *g_xy; float *g_obj, *g_img;
+};
+struct EmitBatch { EmitFrame f[RELOC_BATCH_MAX]; };
+
+__global__ __launch_bounds__(256, 4) void k_db_emit_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids_max,
+                                                          int n_cur_max, int max_rows, int emit_stride, const float *__restrict__ g_pts3d,
+                                                          EmitBatch bt)
+{
+    extern __shared__ u32 lds[];
+    RELOC_SMALL_KERNEL_PRIO();
+    const EmitFrame &F = bt.f[blockIdx.y];
+    ScanMask mask;
+    mask.xyh = nullptr;
+    mask.q[0] = mask.q[1] = mask.q[2] = 0; mask.q[3] = 1;
+    mask.g_pts3d = g_pts3d; mask.g_xy = F.g_xy; mask.g_obj = F.g_obj; mask.g_img = F.g_img;
+    const int C = F.n_cur_p ? min(*F.n_cur_p, n_cur_max) : n_cur_max;
+    db_scan_body<8, true, 4>(lds, C, db, off, F.rec_ids, F.n_ids_p, n_ids_max, F.cur, max_rows, nullptr, F.m_qidx, F.m_tidx, F.m_dist, F.m_n,
+                             emit_stride, mask, nullptr, 0);
+}
+
+int launch_db_emit_batch(reloc_ctx *const *ctxs, int n)
+{
+    reloc_ctx *c0 = ctxs[0];
+    if (n < 1 || n > RELOC_BATCH_MAX) { reloc_set_error("emit batch: 1..%d frames", RELOC_BATCH_MAX); return RELOC_E_ARG; }
+    if (c0->max_feat > 65535 || c0->db_max_rows > MAX_REC_ROWS) { reloc_set_error("emit batch: capacity"); return RELOC_E_CAPACITY; }
+    EmitBatch bt;
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        reloc_ctx *c = ctxs[f < n ? f : 0];
+        EmitFrame &F = bt.f[f];
+        F.rec_ids = c->cand_ids; F.n_ids_p = c->cand_n; F.cur = (const uint4 *)c->f_desc; F.n_cur_p = c->f_count;
+        F.m_qidx = c->m_qidx; F.m_tidx = c->m_tidx; F.m_dist = c->m_dist; F.m_n = c->m_n; F.g_xy = c->f_xy; F.g_obj = c->p_obj; F.g_img = c->p_img;
+    }
+    const int max_rows = c0->db_max_rows < 1 ? 1 : c0->db_max_rows;
+    const int ncb = (c0->max_feat + 511) / 512;
+    const size_t lds = (size_t)(ncb * 512 + max_rows + 16) * 4;
+    if (lds > 160 * 1024) { reloc_set_error("emit batch: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
+    hipLaunchKernelGGL(k_db_emit_batch, dim3(MAX_CAND, n), dim3(256), lds, c0->stream, (const uint4 *)c0->db_desc, c0->db_off, MAX_CAND,
+                       c0->max_feat, max_rows, MAX_REC_ROWS, c0->db_pts3d, bt);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
 // Several frames in ONE launch (BASELINE.json config 4: batched relocalization): workgroup b scans frame b % B -- its
 // current descriptors, feature count, counts array, heading and ticket counters -- so B whole-database scans share one
 // launch: the launch-fixed cost (descriptor prologue per workgroup, last-record tail, kernel boundary) is paid once per
@@ -918,14 +964,14 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
 // One launch for the whole-database scans of n contexts that share a stream and a database (ctxs[0]'s is scanned):
 // frame f = ctxs[f]'s current features, counts into ctxs[f]->db_counts.  q: n x 4 base_link quaternions (heading mask),
 // auto_mode: frames whose local search found candidates stand down on the device.
-int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double cos_tol, bool auto_mode)
+int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double cos_tol, bool auto_mode, bool heading_mask)
 {
     reloc_ctx *c0 = ctxs[0];
     if (n < 1 || n > SCAN_BATCH_MAX) { reloc_set_error("scan batch: 1..%d frames", SCAN_BATCH_MAX); return RELOC_E_ARG; }
     if (c0->max_feat > 65535 || c0->db_max_rows > MAX_REC_ROWS) { reloc_set_error("scan batch: capacity"); return RELOC_E_CAPACITY; }
     ScanBatch bt;
     bt.n = n;
-    bt.xyh = c0->db_xy_heading;
+    bt.xyh = heading_mask ? c0->db_xy_heading : nullptr;
     bt.cos_tol = cos_tol;
     for (int f = 0; f < SCAN_BATCH_MAX; ++f) {
         reloc_ctx *c = ctxs[f < n ? f : 0];
@@ -937,7 +983,9 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     // n_cur_max = the feature capacity; the 8-column kernel walks column blocks of 512 (one block for nfeatures <= 512)
     const int ncb = (c0->max_feat + 511) / 512;
     const size_t lds_all = (size_t)(2 * ncb * 512 + max_rows + 16) * 4;
-    const int resident = c0->num_cu * 4, gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
+    int gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
+    if (c0->scan_batch_gens > 0) gens = c0->scan_batch_gens;
+    const int resident = c0->num_cu * 4;
     // the grid holds `gens` generations in all (not per frame): a workgroup's quota grows with the batch, and with it
     // the share of the launch that is not prologue
     int per_frame = (resident * gens + n - 1) / n;
@@ -1313,20 +1361,32 @@ struct DbBuffers {
 };
 }   // namespace
 
-// Grow the selected arena to at least (cap_records, cap_rows); contents are kept.  All-or-nothing.
-// a shared database is dropped (not freed) before this ctx gets one of its own again
+void db_arrays_drop(DbShare *&share, uint8_t *&desc, float *&pts3d, float *&kp2d, int64_t *&off, double *&pose, double *&xyh)
+{
+    if (share && __atomic_sub_fetch(&share->refs, 1, __ATOMIC_ACQ_REL) == 0) {
+        void *p[] = {desc, pts3d, kp2d, off, pose, xyh};
+        for (void *q : p) if (q) (void)hipFree(q);
+        delete share;
+    }
+    share = nullptr;
+    desc = nullptr; pts3d = nullptr; kp2d = nullptr; off = nullptr; pose = nullptr; xyh = nullptr;
+}
+
+// an adopted database is let go (not freed while anybody else holds it) before this ctx gets one of its own again
 static void db_unshare(reloc_ctx *ctx)
 {
     if (!ctx->db_shared) return;
     if (ctx->db_counts) (void)hipFree(ctx->db_counts);
     if (ctx->topk_part) (void)hipFree(ctx->topk_part);
-    ctx->db_desc = nullptr; ctx->db_pts3d = nullptr; ctx->db_kp2d = nullptr; ctx->db_off = nullptr; ctx->db_pose = nullptr;
-    ctx->db_xy_heading = nullptr; ctx->db_counts = nullptr; ctx->topk_part = nullptr;
+    db_arrays_drop(ctx->db_share, ctx->db_desc, ctx->db_pts3d, ctx->db_kp2d, ctx->db_off, ctx->db_pose, ctx->db_xy_heading);
+    ctx->db_counts = nullptr; ctx->topk_part = nullptr;
     ctx->db_records = ctx->db_rows = ctx->db_cap_records = ctx->db_cap_rows = 0;
     ctx->db_max_rows = 0; ctx->topk_blocks = 0;
     ctx->db_shared = false;
 }
 
+// Grow the selected arena to at least (cap_records, cap_rows); contents are kept.  All-or-nothing.  The old arrays are
+// let go of, not necessarily freed: contexts that adopted them (reloc_db_share) keep scanning them.
 int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
 {
     if (ctx->db_shared) { reloc_set_error("the selected database is shared from another context (read-only here)"); return RELOC_E_STATE; }
@@ -1370,9 +1430,12 @@ int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
                         hipGetErrorString(e));
         return RELOC_E_HIP;
     }
-    DbBuffers old;
-    old.desc = ctx->db_desc; old.pts3d = ctx->db_pts3d; old.kp2d = ctx->db_kp2d; old.off = ctx->db_off; old.pose = ctx->db_pose;
-    old.xyh = ctx->db_xy_heading; old.counts = ctx->db_counts; old.topk = ctx->topk_part;
+    DbShare *fresh = new (std::nothrow) DbShare();
+    if (!fresh) { nb.release(); reloc_set_error("database reserve: out of host memory"); return RELOC_E_HIP; }
+    if (ctx->db_counts) (void)hipFree(ctx->db_counts);
+    if (ctx->topk_part) (void)hipFree(ctx->topk_part);
+    db_arrays_drop(ctx->db_share, ctx->db_desc, ctx->db_pts3d, ctx->db_kp2d, ctx->db_off, ctx->db_pose, ctx->db_xy_heading);
+    ctx->db_share = fresh;
     ctx->db_desc = nb.desc; ctx->db_pts3d = nb.pts3d; ctx->db_kp2d = nb.kp2d; ctx->db_off = nb.off; ctx->db_pose = nb.pose;
     ctx->db_xy_heading = nb.xyh; ctx->db_counts = nb.counts; ctx->topk_part = nb.topk;
     ctx->topk_blocks = blocks;
@@ -1380,7 +1443,6 @@ int db_reserve(reloc_ctx *ctx, int64_t cap_records, int64_t cap_rows)
     ctx->db_cap_rows = cap_rows;
     ctx->db_records = L;
     ctx->db_rows = T;
-    old.release();
     return RELOC_OK;
 }
 
@@ -1409,6 +1471,11 @@ RELOC_API int reloc_db_upload(reloc_ctx *ctx, const uint8_t *desc, const float *
     if (n_records > MAX_DB_RECORDS) { reloc_set_error("database: %lld records (max %lld)", (long long)n_records, (long long)MAX_DB_RECORDS); return RELOC_E_CAPACITY; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     db_unshare(ctx);
+    if (ctx->db_share && __atomic_load_n(&ctx->db_share->refs, __ATOMIC_ACQUIRE) > 1) {
+        // other contexts adopted these arrays: they keep them as they are, this upload goes into fresh ones
+        db_arrays_drop(ctx->db_share, ctx->db_desc, ctx->db_pts3d, ctx->db_kp2d, ctx->db_off, ctx->db_pose, ctx->db_xy_heading);
+        ctx->db_cap_records = ctx->db_cap_rows = 0;
+    }
     // from here on the ctx holds no database until everything below has succeeded
     ctx->db_records = 0;
     ctx->db_rows = 0;
@@ -1484,6 +1551,7 @@ static void db_store_slot(reloc_ctx *ctx)
     a.max_rows = ctx->db_max_rows; a.desc = ctx->db_desc; a.pts3d = ctx->db_pts3d; a.kp2d = ctx->db_kp2d; a.off = ctx->db_off;
     a.pose = ctx->db_pose; a.xy_heading = ctx->db_xy_heading; a.counts = ctx->db_counts; a.topk_part = ctx->topk_part;
     a.topk_blocks = ctx->topk_blocks;
+    a.share = ctx->db_share;
 }
 
 RELOC_API int reloc_db_share(reloc_ctx *dst, reloc_ctx *src)
@@ -1504,9 +1572,12 @@ RELOC_API int reloc_db_share(reloc_ctx *dst, reloc_ctx *src)
     }
     if (dst->db_shared) db_unshare(dst);
     else {
-        void *own[] = {dst->db_desc, dst->db_pts3d, dst->db_kp2d, dst->db_off, dst->db_pose, dst->db_xy_heading, dst->db_counts, dst->topk_part};
-        for (void *q : own) if (q) (void)hipFree(q);
+        if (dst->db_counts) (void)hipFree(dst->db_counts);
+        if (dst->topk_part) (void)hipFree(dst->topk_part);
+        db_arrays_drop(dst->db_share, dst->db_desc, dst->db_pts3d, dst->db_kp2d, dst->db_off, dst->db_pose, dst->db_xy_heading);
     }
+    __atomic_add_fetch(&src->db_share->refs, 1, __ATOMIC_ACQ_REL);
+    dst->db_share = src->db_share;
     dst->db_desc = src->db_desc; dst->db_pts3d = src->db_pts3d; dst->db_kp2d = src->db_kp2d; dst->db_off = src->db_off;
     dst->db_pose = src->db_pose; dst->db_xy_heading = src->db_xy_heading;
     dst->db_counts = counts; dst->topk_part = topk; dst->topk_blocks = blocks;
@@ -1519,8 +1590,8 @@ RELOC_API int reloc_db_share(reloc_ctx *dst, reloc_ctx *src)
 RELOC_API int reloc_db_select(reloc_ctx *ctx, int slot)
 {
     ARG_CHECK_CTX(ctx, slot == 0 || slot == 1, "reloc_db_select: slot must be 0 or 1");
-    if (ctx->db_shared) { reloc_set_error("reloc_db_select: the selected database is shared; upload or share per slot instead"); return RELOC_E_STATE; }
     if (slot == ctx->db_sel) return RELOC_OK;
+    if (ctx->db_shared) { reloc_set_error("reloc_db_select: the selected database is shared; upload or share per slot instead"); return RELOC_E_STATE; }
     db_store_slot(ctx);
     const DbArena &a = ctx->db_slot[slot];
     ctx->db_sel = slot;
@@ -1528,6 +1599,7 @@ RELOC_API int reloc_db_select(reloc_ctx *ctx, int slot)
     ctx->db_max_rows = a.max_rows; ctx->db_desc = a.desc; ctx->db_pts3d = a.pts3d; ctx->db_kp2d = a.kp2d; ctx->db_off = a.off;
     ctx->db_pose = a.pose; ctx->db_xy_heading = a.xy_heading; ctx->db_counts = a.counts; ctx->topk_part = a.topk_part;
     ctx->topk_blocks = a.topk_blocks;
+    ctx->db_share = a.share;
     return RELOC_OK;
 }
 

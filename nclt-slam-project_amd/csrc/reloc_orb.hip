@@ -101,6 +101,16 @@ static_assert(sizeof(PyrTile) == 128, "PyrTile is read as 8 dwordx4");
 
 struct PyrLds { int lev[NLEV]; int tabs; };    // byte offsets of the level buffers and of the table slices in LDS
 
+// Frame-batched launches (reloc_tick_batch_dev, the sharded halves): the five ORB kernels of up to 8 contexts as FIVE
+// launches, blockIdx.y = frame.  Everything a kernel needs of one context travels in the kernel arguments.
+struct OrbFrame {
+    const OrbTable *tab; const PyrTile *tiles; const int32_t *rz; const uint8_t *src;
+    uint8_t *pyr, *nms, *blur; int32_t *hist, *cand_cnt; u32 *cand_key; float *cand_resp; int32_t *dbg_cut;
+    int32_t *kp_cnt; u32 *kp_key; float *kp_resp; float *f_xy, *f_size, *f_angle, *f_resp; int32_t *f_oct; uint8_t *f_desc;
+    int32_t *f_count;
+};
+struct OrbBatch { OrbFrame f[RELOC_BATCH_MAX]; };
+
 // gray value of 4 pixels from 12 interleaved bytes / a gray dword
 template <int CH, bool ALIGNED>
 __device__ __forceinline__ void pyr_fetch(const uint8_t *sp, int x4, int w, u32 (&d)[3])
@@ -165,12 +175,11 @@ __device__ __forceinline__ int pyr_div(int q, float inv) { return (int)(((float)
 // neighbour of a scan (a 256-thread workgroup fits into the slot one retiring scan workgroup frees: 4-stream run 6550 ->
 // 6685 frames/s, synchronous tick +6 us), so both exist: see orb_run_dev.
 template <int CH, bool ALIGNED, int PYR_BS>
-__global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,
+__device__ __forceinline__ void pyramid_body(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,
                                                  const int32_t *__restrict__ rz, const uint8_t *__restrict__ src, int w, int h,
                                                  int sstride, int order_rgb, uint8_t *__restrict__ pyr, PyrLds lds,
                                                  int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     extern __shared__ u32 s_pyr[];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
@@ -291,6 +300,23 @@ __global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__
         }
     }
 }
+template <int CH, bool ALIGNED, int PYR_BS>
+__global__ __launch_bounds__(PYR_BS) void k_pyramid(const OrbTable *__restrict__ tab, const PyrTile *__restrict__ tiles,
+                                                 const int32_t *__restrict__ rz, const uint8_t *__restrict__ src, int w, int h,
+                                                 int sstride, int order_rgb, uint8_t *__restrict__ pyr, PyrLds lds,
+                                                 int32_t *__restrict__ hist, int32_t *__restrict__ cand_cnt)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    pyramid_body<CH, ALIGNED, PYR_BS>(tab, tiles, rz, src, w, h, sstride, order_rgb, pyr, lds, hist, cand_cnt);
+}
+template <int CH, bool ALIGNED, int PYR_BS>
+__global__ __launch_bounds__(PYR_BS) void k_pyramid_batch(OrbBatch b, int w, int h, int sstride, int order_rgb, PyrLds lds)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const OrbFrame &F = b.f[blockIdx.y];
+    pyramid_body<CH, ALIGNED, PYR_BS>(F.tab, F.tiles, F.rz, F.src, w, h, sstride, order_rgb, F.pyr, lds, F.hist, F.cand_cnt);
+}
+
 
 // ---- blur ---------------------------------------------------------------------------------------
 constexpr int BT_W = 64, BT_H = 16;
@@ -490,6 +516,14 @@ __global__ __launch_bounds__(256) void k_fast_blur(const OrbTable *__restrict__ 
     if ((int)blockIdx.x < n_fast) fast_nms_tile(tab, pyr, nms, hist, (int)blockIdx.x);
     else blur7_tile(tab, pyr, blur, (int)blockIdx.x - n_fast);
 }
+__global__ __launch_bounds__(256) void k_fast_blur_batch(OrbBatch b, int n_fast)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const OrbFrame &F = b.f[blockIdx.y];
+    if ((int)blockIdx.x < n_fast) fast_nms_tile(F.tab, F.pyr, F.nms, F.hist, (int)blockIdx.x);
+    else blur7_tile(F.tab, F.pyr, F.blur, (int)blockIdx.x - n_fast);
+}
+
 
 // cut score from the level's histogram (KeyPointsFilter::retainBest(2*quota) with ties kept, raised
 // while the kept set exceeds RELOC_ORB_STAGE1_CAP), by ONE wave without block barriers: lane i owns the
@@ -559,12 +593,11 @@ __device__ __forceinline__ float harris_finish(int a, int b, int c)
 // compute their Harris responses (one wave per survivor) and append them to the level's candidate list.
 // Corners cluster, and a block works through its survivors four at a time: small chunks keep the longest
 // block short (ORB stage 77.5 us with 4096-byte chunks, 75.7 us with 1024-byte chunks).
-__global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+__device__ __forceinline__ void harris_body(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
                                                 const uint8_t *__restrict__ nms, const int32_t *__restrict__ hist,
                                                 int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
                                                 float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     __shared__ int s_cut;
     __shared__ int s_n, s_base;
     __shared__ u32 s_list[HARRIS_CHUNK];
@@ -647,17 +680,31 @@ __global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab
         }
     }
 }
+__global__ __launch_bounds__(256) void k_harris(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                const uint8_t *__restrict__ nms, const int32_t *__restrict__ hist,
+                                                int32_t *__restrict__ cand_cnt, u32 *__restrict__ cand_key,
+                                                float *__restrict__ cand_resp, int32_t *__restrict__ dbg_cut)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    harris_body(tab, pyr, nms, hist, cand_cnt, cand_key, cand_resp, dbg_cut);
+}
+__global__ __launch_bounds__(256) void k_harris_batch(OrbBatch b)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const OrbFrame &F = b.f[blockIdx.y];
+    harris_body(F.tab, F.pyr, F.nms, F.hist, F.cand_cnt, F.cand_key, F.cand_resp, F.dbg_cut);
+}
+
 
 // ---- stage 2: best quota by Harris (ties kept), raster order -----------------------------------
 // One workgroup per level.  Element i is kept iff fewer than `quota` responses are strictly greater
 // (= best quota plus every tie of the quota-th); the kept ones are then placed in raster order by
 // counting smaller keys.  Quadratic in the list length, which is ~2*quota (a few hundred).
-__global__ __launch_bounds__(1024) void k_select(const OrbTable *__restrict__ tab, const int32_t *__restrict__ cand_cnt,
+__device__ __forceinline__ void select_body(const OrbTable *__restrict__ tab, const int32_t *__restrict__ cand_cnt,
                                                  const u32 *__restrict__ cand_key, const float *__restrict__ cand_resp,
                                                  int32_t *__restrict__ kp_cnt, u32 *__restrict__ kp_key,
                                                  float *__restrict__ kp_resp)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     __shared__ u32 s_key[RELOC_ORB_STAGE1_CAP];
     __shared__ float s_resp[RELOC_ORB_STAGE1_CAP];
     __shared__ u32 s_kidx[RELOC_ORB_STAGE1_CAP];
@@ -690,6 +737,21 @@ __global__ __launch_bounds__(1024) void k_select(const OrbTable *__restrict__ ta
     }
     if (tid == 0) kp_cnt[l] = K;
 }
+__global__ __launch_bounds__(1024) void k_select(const OrbTable *__restrict__ tab, const int32_t *__restrict__ cand_cnt,
+                                                 const u32 *__restrict__ cand_key, const float *__restrict__ cand_resp,
+                                                 int32_t *__restrict__ kp_cnt, u32 *__restrict__ kp_key,
+                                                 float *__restrict__ kp_resp)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    select_body(tab, cand_cnt, cand_key, cand_resp, kp_cnt, kp_key, kp_resp);
+}
+__global__ __launch_bounds__(1024) void k_select_batch(OrbBatch b)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const OrbFrame &F = b.f[blockIdx.y];
+    select_body(F.tab, F.cand_cnt, F.cand_key, F.cand_resp, F.kp_cnt, F.kp_key, F.kp_resp);
+}
+
 
 // ---- orientation + descriptor -------------------------------------------------------------------
 __device__ float fast_atan2_deg(float y, float x)
@@ -751,7 +813,7 @@ __device__ void sincos_spec(double th, float *s_out, float *c_out)
 }
 
 // one wave per keypoint; block = 4 waves
-__global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+__device__ __forceinline__ void describe_body(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
                                                   const uint8_t *__restrict__ blur, const int32_t *__restrict__ kp_cnt,
                                                   const u32 *__restrict__ kp_key, const float *__restrict__ kp_resp,
                                                   int max_feat, float *__restrict__ f_xy, float *__restrict__ f_size,
@@ -759,7 +821,6 @@ __global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ t
                                                   int32_t *__restrict__ f_oct, uint8_t *__restrict__ f_desc,
                                                   int32_t *__restrict__ f_count)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     int base[NLEV + 1];
@@ -826,6 +887,25 @@ __global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ t
         f_oct[g] = l;
     }
 }
+__global__ __launch_bounds__(256) void k_describe(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
+                                                  const uint8_t *__restrict__ blur, const int32_t *__restrict__ kp_cnt,
+                                                  const u32 *__restrict__ kp_key, const float *__restrict__ kp_resp,
+                                                  int max_feat, float *__restrict__ f_xy, float *__restrict__ f_size,
+                                                  float *__restrict__ f_angle, float *__restrict__ f_resp,
+                                                  int32_t *__restrict__ f_oct, uint8_t *__restrict__ f_desc,
+                                                  int32_t *__restrict__ f_count)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    describe_body(tab, pyr, blur, kp_cnt, kp_key, kp_resp, max_feat, f_xy, f_size, f_angle, f_resp, f_oct, f_desc, f_count);
+}
+__global__ __launch_bounds__(256) void k_describe_batch(OrbBatch b, int max_feat)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const OrbFrame &F = b.f[blockIdx.y];
+    describe_body(F.tab, F.pyr, F.blur, F.kp_cnt, F.kp_key, F.kp_resp, max_feat, F.f_xy, F.f_size, F.f_angle, F.f_resp, F.f_oct, F.f_desc,
+                  F.f_count);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 static void resize_axis(int src_n, int dst_n, int32_t *ofs, int32_t *coef)
@@ -1000,6 +1080,53 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
+
+// The same five kernels for n contexts (one frame each, equal geometry) that share a stream: five launches, blockIdx.y = frame.
+int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_dev, int w, int h, int stride, int order, int nfeatures)
+{
+    if (n < 1 || n > RELOC_BATCH_MAX) { reloc_set_error("orb batch: 1..%d frames", RELOC_BATCH_MAX); return RELOC_E_ARG; }
+    OrbBatch b;
+    bool aligned = (w % 4 == 0) && (stride % 4 == 0);
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        reloc_ctx *c = ctxs[f < n ? f : 0];
+        if (f < n) {
+            const int rc = orb_prepare(c, w, h, nfeatures);
+            if (rc) return rc;
+            if (c->pyr_ntiles != ctxs[0]->pyr_ntiles || c->pyr_lds_bytes != ctxs[0]->pyr_lds_bytes || c->max_feat != ctxs[0]->max_feat) {
+                reloc_set_error("orb batch: contexts of unequal geometry");
+                return RELOC_E_STATE;
+            }
+            aligned = aligned && (((uintptr_t)srcs_dev[f]) % 4 == 0);
+        }
+        OrbFrame &F = b.f[f];
+        F.tab = (const OrbTable *)c->orb_const; F.tiles = (const PyrTile *)c->pyr_tiles; F.rz = c->rz_tab; F.src = srcs_dev[f < n ? f : 0];
+        F.pyr = c->pyr; F.nms = c->nms; F.blur = c->blur; F.hist = c->hist; F.cand_cnt = c->cand_cnt; F.cand_key = c->cand_key;
+        F.cand_resp = c->cand_resp; F.dbg_cut = c->dbg_cut; F.kp_cnt = c->kp_cnt; F.kp_key = c->kp_key; F.kp_resp = c->kp_resp;
+        F.f_xy = c->f_xy; F.f_size = c->f_size; F.f_angle = c->f_angle; F.f_resp = c->f_resp; F.f_oct = c->f_oct; F.f_desc = c->f_desc;
+        F.f_count = c->f_count;
+    }
+    reloc_ctx *c0 = ctxs[0];
+    const OrbTable *tab_h = (const OrbTable *)c0->orb_tab_host;
+    hipStream_t st = c0->stream;
+    reloc_prof_begin(c0, RELOC_PROF_ORB);
+    PyrLds lds;
+    for (int l = 0; l < NLEV; ++l) lds.lev[l] = c0->pyr_lds[l];
+    lds.tabs = c0->pyr_lds[NLEV];
+    // 256-thread pyramid: a batch runs beside other streams' scans (see orb_run_dev)
+    if (aligned)
+        hipLaunchKernelGGL((k_pyramid_batch<3, true, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, order, lds);
+    else
+        hipLaunchKernelGGL((k_pyramid_batch<3, false, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, order, lds);
+    hipLaunchKernelGGL(k_fast_blur_batch, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV], n), dim3(256), 0, st, b,
+                       tab_h->fast_tile_base[NLEV]);
+    hipLaunchKernelGGL(k_harris_batch, dim3(tab_h->flat_base[NLEV], n), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_select_batch, dim3(NLEV, n), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(k_describe_batch, dim3((c0->max_feat + 3) / 4, n), dim3(256), 0, st, b, c0->max_feat);
+    reloc_prof_end(c0, RELOC_PROF_ORB);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 RELOC_API int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, int stride, int order, uint8_t *gray)

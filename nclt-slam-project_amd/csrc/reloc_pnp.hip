@@ -241,12 +241,18 @@ struct PnpParams {
     int min_m;       // fewer correspondences than this => no model (matcher gate M:330, or 4)
 };
 
+// Frame-batched launches (reloc_tick_batch_dev, the sharded halves): the candidates of up to 8 contexts in one launch per
+// kernel; the frame is the last grid dimension.
+struct PnpFrame {
+    const float *obj, *img; const int32_t *m_arr, *n_cand_p; double *Rt; int32_t *cnt, *inl; PnpOut *out; uint64_t seed;
+};
+struct PnpBatch { PnpFrame f[RELOC_BATCH_MAX]; };
+
 // grid (ceil(iters/64), n_cand_max), block 64
-__global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
-                                                const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
-                                                PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
+__device__ __forceinline__ void pnp_hyp_body(const float *__restrict__ obj, const float *__restrict__ img,
+                                             const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                             const PnpParams &prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
     const int h = blockIdx.x * 64 + threadIdx.x;
@@ -276,14 +282,29 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, c
     for (int k = 0; k < 12; ++k) out[k] = sols[12 * best + k];
     *cn = 0;
 }
-
-// grid (iters, n_cand_max), block 64: one wave scores one hypothesis
-__global__ __launch_bounds__(64) void k_pnp_score(const float *__restrict__ obj, const float *__restrict__ img,
-                                                  const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
-                                                  PnpParams prm, const double *__restrict__ Rt_in,
-                                                  int32_t *__restrict__ cnt, uint8_t *__restrict__ mask, int hyp_stride)
+__global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
+                                                const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
 {
     RELOC_SMALL_KERNEL_PRIO();
+    pnp_hyp_body(obj, img, m_arr, n_cand_p, prm, Rt_out, cnt);
+}
+// grid (ceil(iters/64), n_cand_max, frames)
+__global__ __launch_bounds__(64) void k_pnp_hyp_batch(PnpBatch b, PnpParams prm)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const PnpFrame &F = b.f[blockIdx.z];
+    prm.seed = F.seed;
+    pnp_hyp_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt);
+}
+
+
+// grid (iters, n_cand_max), block 64: one wave scores one hypothesis
+__device__ __forceinline__ void pnp_score_body(const float *__restrict__ obj, const float *__restrict__ img,
+                                               const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                               const PnpParams &prm, const double *__restrict__ Rt_in,
+                                               int32_t *__restrict__ cnt, uint8_t *__restrict__ mask, int hyp_stride)
+{
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
     const int h = blockIdx.x;
@@ -304,6 +325,22 @@ __global__ __launch_bounds__(64) void k_pnp_score(const float *__restrict__ obj,
     }
     if (threadIdx.x == 0) *cn = count;
 }
+__global__ __launch_bounds__(64) void k_pnp_score(const float *__restrict__ obj, const float *__restrict__ img,
+                                                  const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                  PnpParams prm, const double *__restrict__ Rt_in,
+                                                  int32_t *__restrict__ cnt, uint8_t *__restrict__ mask, int hyp_stride)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    pnp_score_body(obj, img, m_arr, n_cand_p, prm, Rt_in, cnt, mask, hyp_stride);
+}
+// grid (iters, n_cand_max, frames)
+__global__ __launch_bounds__(64) void k_pnp_score_batch(PnpBatch b, PnpParams prm, int hyp_stride)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const PnpFrame &F = b.f[blockIdx.z];
+    pnp_score_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt, nullptr, hyp_stride);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 __device__ void rodrigues_exp(const double w[3], double R[9])
@@ -509,14 +546,12 @@ __device__ bool chol_solve6(const double Ain[36], const double b[6], double x[6]
 // 4-stream run 5940 -> 6020 frames/s, synchronous tick +1.7 us.  80 registers: no further gain, tick +16 us.
 // (The same limit on k_pnp_hyp (108 -> 80) and k_pyramid (81 -> 64) changes nothing.)  Ticks that run no whole-database scan
 // and the single-call entry point use the unconstrained instantiation (ctx->latency_shapes).
-template <int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
-                                                   const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
-                                                   PnpParams prm, const double *__restrict__ Rt_all,
-                                                   const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
-                                                   PnpOut *__restrict__ out)
+__device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, const float *__restrict__ img,
+                                                const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                const PnpParams &prm, const double *__restrict__ Rt_all,
+                                                const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
+                                                PnpOut *__restrict__ out)
 {
-    RELOC_SMALL_KERNEL_PRIO();
     const int c = blockIdx.x;
     if (n_cand_p && c >= *n_cand_p) return;
     const int lane = threadIdx.x;
@@ -634,6 +669,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
         po.n_matches = m;
     }
 }
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
+                                                   const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
+                                                   PnpParams prm, const double *__restrict__ Rt_all,
+                                                   const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
+                                                   PnpOut *__restrict__ out)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    pnp_finish_body(obj, img, m_arr, n_cand_p, prm, Rt_all, cnt, inl_out, out);
+}
+// grid (n_cand_max, frames)
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_pnp_finish_batch(PnpBatch b, PnpParams prm)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const PnpFrame &F = b.f[blockIdx.y];
+    prm.seed = F.seed;
+    pnp_finish_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt, F.inl, F.out);
+}
+
 
 static PnpParams make_params(const double K4[4], int iters, float thr_px, double conf, uint64_t seed, int stride,
                              int min_m)
@@ -673,6 +728,34 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
+
+// the candidates of n contexts (one shared stream, equal parameters) in three launches
+int pnp_run_candidates_batch(reloc_ctx *const *ctxs, int n, int n_cand_max, const uint64_t *seeds)
+{
+    reloc_ctx *c0 = ctxs[0];
+    const int iters = c0->prm.ransac_iterations;
+    if (n < 1 || n > RELOC_BATCH_MAX || n_cand_max <= 0 || n_cand_max > MAX_CAND || iters < 1 || iters > MAX_HYP) {
+        reloc_set_error("pnp batch: n %d n_cand %d (max %d) iters %d (max %d)", n, n_cand_max, MAX_CAND, iters, MAX_HYP);
+        return RELOC_E_CAPACITY;
+    }
+    const PnpParams prm = make_params(c0->K4, iters, (float)c0->prm.ransac_reproj_px, c0->prm.ransac_confidence, 0, MAX_REC_ROWS,
+                                      c0->prm.min_matches);
+    PnpBatch b;
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        reloc_ctx *c = ctxs[f < n ? f : 0];
+        PnpFrame &F = b.f[f];
+        F.obj = c->p_obj; F.img = c->p_img; F.m_arr = c->m_n; F.n_cand_p = c->cand_n; F.Rt = c->p_Rt; F.cnt = c->p_cnt; F.inl = c->p_inl;
+        F.out = c->p_out; F.seed = seeds ? seeds[f < n ? f : 0] : 0;
+    }
+    reloc_prof_begin(c0, RELOC_PROF_PNP);
+    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3((iters + 63) / 64, n_cand_max, n), dim3(64), 0, c0->stream, b, prm);
+    hipLaunchKernelGGL(k_pnp_score_batch, dim3(iters, n_cand_max, n), dim3(64), 0, c0->stream, b, prm, MAX_HYP);
+    hipLaunchKernelGGL(k_pnp_finish_batch<4>, dim3(n_cand_max, n), dim3(64), 0, c0->stream, b, prm);
+    reloc_prof_end(c0, RELOC_PROF_PNP);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 RELOC_API int reloc_pnp_score(reloc_ctx *ctx, const float *obj, const float *img, int m, const double *Rt, int H,

@@ -233,17 +233,17 @@ __global__ __launch_bounds__(TICK_BLOCK) void k_candidates_local(const double *_
 // skip_if: RELOC_TICK_AUTO -- the local search found candidates (*skip_if != 0): they stand, nothing is ranked (the scan
 // before this kernel has skipped itself the same way).  relocating: set when this ranking produced the list.
 constexpr int TOPK_HIST_THREADS = 1024;
-__global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base,
-                                                                   int min_matches, int max_count, int32_t *__restrict__ out_ids,
-                                                                   int32_t *__restrict__ out_counts, int32_t *__restrict__ out_n,
-                                                                   const int32_t *skip_if, int32_t *__restrict__ relocating)
-{
-    RELOC_SMALL_KERNEL_PRIO();
+__device__ __forceinline__ void topk_counts_body(const int32_t *__restrict__ counts, int L, int k, int id_base,
+                                                 int min_matches, int max_count, int32_t *__restrict__ out_ids,
+                                                 int32_t *__restrict__ out_counts, int32_t *out_n,
+                                                 const int32_t *skip_if, int32_t *__restrict__ relocating,
+                                                 const int32_t *__restrict__ f_count, int32_t *__restrict__ out_nfeat){
     extern __shared__ int s_hist[];                     // max_count + 2 bins
+    if (out_nfeat && threadIdx.x == 0) *out_nfeat = *f_count;          // sharded scan: the frame's feature count rides along
     __shared__ int s_wave[16];
     __shared__ int s_cstar, s_above, s_nlist;
     __shared__ unsigned long long s_list[TOPK_MAX];
-    if (skip_if && *skip_if != 0) return;               // block-uniform; out_n (may alias skip_if) is written last
+    if (skip_if && *skip_if != 0) return;               // block-uniform; out_n may BE skip_if (AUTO mode): neither is __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i <= max_count + 1; i += TOPK_HIST_THREADS) s_hist[i] = 0;
     if (tid == 0) s_nlist = 0;
@@ -325,6 +325,30 @@ __global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t
         }
     }
 }
+__global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts(const int32_t *__restrict__ counts, int L, int k, int id_base,
+                                                                   int min_matches, int max_count, int32_t *__restrict__ out_ids,
+                                                                   int32_t *__restrict__ out_counts, int32_t *out_n,
+                                                                   const int32_t *skip_if, int32_t *__restrict__ relocating,
+                                                                   const int32_t *__restrict__ f_count = nullptr,
+                                                                   int32_t *__restrict__ out_nfeat = nullptr)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    topk_counts_body(counts, L, k, id_base, min_matches, max_count, out_ids, out_counts, out_n, skip_if, relocating, f_count, out_nfeat);
+}
+// the rankings of up to 8 frames in one launch: block = frame
+struct TopkFrame {
+    const int32_t *counts; int32_t *out_ids, *out_counts, *out_n; const int32_t *skip_if; int32_t *relocating; const int32_t *f_count;
+    int32_t *out_nfeat;
+};
+struct TopkBatch { TopkFrame f[RELOC_BATCH_MAX]; };
+__global__ __launch_bounds__(TOPK_HIST_THREADS) void k_topk_counts_batch(TopkBatch b, int L, int k, int id_base, int min_matches, int max_count)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const TopkFrame &F = b.f[blockIdx.x];
+    topk_counts_body(F.counts, L, k, id_base, min_matches, max_count, F.out_ids, F.out_counts, F.out_n, F.skip_if, F.relocating, F.f_count,
+                     F.out_nfeat);
+}
+
 
 // Local candidates in ONE launch (databases up to NEAR_MAX_RECORDS).  Only a record within radius_m can become a
 // candidate, and the nearest-15 cut (M:296) is taken in LocalKey order, which is monotone in the distance at 44-bit
@@ -426,26 +450,26 @@ static void launch_candidates_local(reloc_ctx *ctx, const TickParams &prm)
 }
 
 // auto_mode: the ranking only takes effect when the local search left no candidate (see k_topk_counts)
-static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts, bool auto_mode)
+static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t *out_counts, bool auto_mode, int id_base = 0,
+                               int32_t *out_nfeat = nullptr)
 {
     const int L = (int)ctx->db_records;
     // a count cannot exceed the rows of the largest record nor the features of a frame
     const int max_count = ctx->db_max_rows < ctx->max_feat ? ctx->db_max_rows : ctx->max_feat;
     hipLaunchKernelGGL(k_topk_counts, dim3(1), dim3(TOPK_HIST_THREADS), (size_t)(max_count + 2) * sizeof(int), ctx->stream, ctx->db_counts,
-                       L, k, 0, ctx->prm.min_matches, max_count, out_ids, out_counts, ctx->cand_n,
-                       auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr, ctx->tick_flags);
+                       L, k, id_base, ctx->prm.min_matches, max_count, out_ids, out_counts, ctx->cand_n,
+                       auto_mode ? (const int32_t *)ctx->cand_n : (const int32_t *)nullptr, ctx->tick_flags,
+                       (const int32_t *)ctx->f_count, out_nfeat);
 }
 
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
 // one lane per candidate composes its pose; the best (most inliers, first on ties) is picked by a wave
 // reduction.
-__global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
-                                                      const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
-                                                      const int32_t *__restrict__ f_count, TickParams prm,
-                                                      const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
-                                                      TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext)
-{
-    RELOC_SMALL_KERNEL_PRIO();
+__device__ __forceinline__ void tick_finalize_body(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
+                                                   const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
+                                                   const int32_t *__restrict__ f_count, const TickParams &prm,
+                                                   const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
+                                                   TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext){
     // res: the device record (read by the accumulation and by device-side consumers); res_host: the ctx's own record in
     // pinned host memory, what reloc_tick_result() reads after the stream has drained -- the kernel writes it over PCIe
     // itself, which takes a 5 us copy kernel (and its launch) out of every synchronous tick; res_ext: a caller-named pinned
@@ -523,6 +547,29 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
         if (res_ext) *res_ext = out;
     }
 }
+__global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
+                                                      const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
+                                                      const int32_t *__restrict__ f_count, TickParams prm,
+                                                      const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
+                                                      TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    tick_finalize_body(cand_ids, cand_n, pnp, db_pose, f_count, prm, relocating_p, res, res_host, res_ext);
+}
+// the finalisation of up to 8 frames in one launch: block = frame; prm carries what the frames share, F.base_pose the rest
+struct FinalFrame {
+    const int32_t *cand_ids, *cand_n; const PnpOut *pnp; const int32_t *f_count, *relocating; TickResult *res, *res_host, *res_ext;
+    double base_pose[7];
+};
+struct FinalBatch { FinalFrame f[RELOC_BATCH_MAX]; };
+__global__ __launch_bounds__(64) void k_tick_finalize_batch(FinalBatch b, const double *__restrict__ db_pose, TickParams prm)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    const FinalFrame &F = b.f[blockIdx.x];
+    for (int k = 0; k < 7; ++k) prm.base_pose[k] = F.base_pose[k];
+    tick_finalize_body(F.cand_ids, F.cand_n, F.pnp, db_pose, F.f_count, prm, F.relocating, F.res, F.res_host, F.res_ext);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 static double heading_cos_tol_host(const reloc_ctx *ctx) { return cos(ctx->prm.heading_tol_deg * 3.14159265358979323846 / 180.0); }
@@ -615,6 +662,51 @@ static int tick_end(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
     return tick_solve(ctx, prm, seed);
 }
 
+// ---- frame-batched forms: n contexts on one stream, every stage ONE launch (blockIdx = frame) -----------------
+// scan_rows != NULL (sharded scan half): frame f's list goes to row f of scan_rows (2k + 2 int32: k ids, k counts, feature
+// count, 0) with id_base added; otherwise it becomes the frame's candidate list.
+static void launch_topk_counts_batch(reloc_ctx *const *ctxs, int n, int k, bool auto_mode, int id_base, int32_t *scan_rows)
+{
+    reloc_ctx *c0 = ctxs[0];
+    const int max_count = c0->db_max_rows < c0->max_feat ? c0->db_max_rows : c0->max_feat;
+    TopkBatch b;
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        reloc_ctx *c = ctxs[f < n ? f : 0];
+        TopkFrame &F = b.f[f];
+        int32_t *row = scan_rows ? scan_rows + (size_t)(f < n ? f : 0) * (2 * k + 2) : nullptr;
+        F.counts = c->db_counts;
+        F.out_ids = row ? row : c->cand_ids; F.out_counts = row ? row + k : nullptr; F.out_n = c->cand_n;
+        F.skip_if = auto_mode ? (const int32_t *)c->cand_n : (const int32_t *)nullptr;
+        F.relocating = c->tick_flags; F.f_count = c->f_count; F.out_nfeat = row ? row + 2 * k : nullptr;
+    }
+    hipLaunchKernelGGL(k_topk_counts_batch, dim3(n), dim3(TOPK_HIST_THREADS), (size_t)(max_count + 2) * sizeof(int), c0->stream, b,
+                       (int)c0->db_records, k, id_base, c0->prm.min_matches, max_count);
+}
+
+// emit pass + PnP + finalisation of n frames: 1 + 3 + 1 launches.  res_ext_base != NULL: frame f's record also goes to
+// res_ext_base + f (device or pinned memory) instead of the context's reloc_tick_result_to target.
+static int tick_solve_batch(reloc_ctx *const *ctxs, int n, const double *base_poses, int mode, int check_consistency,
+                            const uint64_t *seeds, TickResult *res_ext_base)
+{
+    int rc;
+    if ((rc = launch_db_emit_batch(ctxs, n))) return rc;
+    if ((rc = pnp_run_candidates_batch(ctxs, n, MAX_CAND, seeds))) return rc;
+    reloc_ctx *c0 = ctxs[0];
+    const TickParams prm = make_tick_params(c0, base_poses, mode, check_consistency);
+    FinalBatch b;
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        const int g = f < n ? f : 0;
+        reloc_ctx *c = ctxs[g];
+        FinalFrame &F = b.f[f];
+        F.cand_ids = c->cand_ids; F.cand_n = c->cand_n; F.pnp = c->p_out; F.f_count = c->f_count; F.relocating = c->tick_flags;
+        F.res = c->tick_res; F.res_host = c->tick_res_host; F.res_ext = res_ext_base ? res_ext_base + g : c->tick_res_ext;
+        for (int k = 0; k < 7; ++k) F.base_pose[k] = base_poses[7 * g + k];
+    }
+    hipLaunchKernelGGL(k_tick_finalize_batch, dim3(n), dim3(64), 0, c0->stream, b, c0->db_pose, prm);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
 RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                              int global_reloc, uint64_t seed)
 {
@@ -638,31 +730,35 @@ RELOC_API int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t 
         ARG_CHECK(c && imgs_dev[f], "reloc_tick_batch_dev: NULL context or frame");
         if (!db_ready(c)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
         if (c->stream != ctxs[0]->stream || c->device != ctxs[0]->device || c->db_desc != ctxs[0]->db_desc ||
-            c->db_records != ctxs[0]->db_records || c->max_feat != ctxs[0]->max_feat) {
+            c->db_records != ctxs[0]->db_records || c->max_feat != ctxs[0]->max_feat ||
+            memcmp(&c->prm, &ctxs[0]->prm, sizeof(reloc_params)) != 0 || memcmp(c->K4, ctxs[0]->K4, sizeof(c->K4)) != 0 ||
+            memcmp(c->b2c_t, ctxs[0]->b2c_t, sizeof(c->b2c_t)) != 0 || memcmp(c->b2c_R, ctxs[0]->b2c_R, sizeof(c->b2c_R)) != 0) {
             reloc_set_error("tick batch: the contexts must share one stream (reloc_set_stream), one device and one database "
-                            "(reloc_db_share) and have equal feature capacity");
+                            "(reloc_db_share) and have equal feature capacity, matcher parameters (reloc_set_params) and camera (reloc_set_camera)");
             return RELOC_E_STATE;
         }
         for (int g = 0; g < f; ++g) ARG_CHECK(ctxs[g] != c, "reloc_tick_batch_dev: a context appears twice");
     }
     (void)hipSetDevice(ctxs[0]->device);
     int rc;
-    TickParams prm[8];
     double q[8 * 4];
-    for (int f = 0; f < n; ++f) {
-        prm[f] = make_tick_params(ctxs[f], base_poses + 7 * f, global_reloc, -1);
+    for (int f = 0; f < n; ++f)
         for (int k = 0; k < 4; ++k) q[4 * f + k] = base_poses[7 * f + 3 + k];
-        if ((rc = tick_begin(ctxs[f], imgs_dev[f], w, h, order, prm[f]))) return rc;
-    }
+    // every stage of the batch is ONE launch with the frame as a grid dimension: ORB 5, local candidates n (LOCAL / AUTO
+    // only), scan 1, ranking 1, emit 1, PnP 3, finalisation 1 -- 12 launches for 8 frames in whole-database mode instead
+    // of the 100 of eight per-frame ticks (their serial chain of small kernels was what a batch spent its time on)
+    if ((rc = orb_run_batch_dev(ctxs, n, imgs_dev, w, h, w * 3, order, ctxs[0]->prm.nfeatures))) return rc;
+    const TickParams prm0 = make_tick_params(ctxs[0], base_poses, global_reloc, -1);
+    if (global_reloc != RELOC_TICK_GLOBAL)
+        for (int f = 0; f < n; ++f) launch_candidates_local(ctxs[f], make_tick_params(ctxs[f], base_poses + 7 * f, global_reloc, -1));
     if (global_reloc != RELOC_TICK_LOCAL) {
         reloc_prof_begin(ctxs[0], RELOC_PROF_DB_SCAN);
-        rc = launch_db_scan_batch(ctxs, n, q, prm[0].cos_tol, global_reloc == RELOC_TICK_AUTO);
+        rc = launch_db_scan_batch(ctxs, n, q, prm0.cos_tol, global_reloc == RELOC_TICK_AUTO);
         reloc_prof_end(ctxs[0], RELOC_PROF_DB_SCAN);
         if (rc) return rc;
+        launch_topk_counts_batch(ctxs, n, ctxs[0]->prm.global_max_candidates, global_reloc == RELOC_TICK_AUTO, 0, nullptr);
     }
-    for (int f = 0; f < n; ++f)
-        if ((rc = tick_end(ctxs[f], prm[f], seeds ? seeds[f] : 0))) return rc;
-    return RELOC_OK;
+    return tick_solve_batch(ctxs, n, base_poses, global_reloc, -1, seeds, nullptr);
 }
 
 RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj, int32_t *lm_idx,
@@ -754,6 +850,19 @@ __global__ void k_set_candidates(const int32_t *__restrict__ ids, int n, int32_t
     }
 }
 
+struct SetCandBatch { int32_t *cand_ids[RELOC_BATCH_MAX], *cand_n[RELOC_BATCH_MAX], *flags[RELOC_BATCH_MAX]; };
+__global__ void k_set_candidates_batch(const int32_t *__restrict__ ids, int k, SetCandBatch b, int flag)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int m = 0;
+        for (int i = 0; i < k; ++i)
+            if (ids[f * k + i] >= 0) b.cand_ids[f][m++] = ids[f * k + i];
+        *b.cand_n[f] = m;
+        *b.flags[f] = flag;
+    }
+}
+
 RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand, const double base_pose[7],
                                    int check_consistency, uint64_t seed)
 {
@@ -765,6 +874,117 @@ RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, 
     hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, ctx->stream, ctx->tick_flags, check_consistency ? 0 : 1);
     const TickParams prm = make_tick_params(ctx, base_pose, check_consistency ? RELOC_TICK_LOCAL : RELOC_TICK_GLOBAL, check_consistency);
     return tick_solve(ctx, prm, seed);
+}
+
+// ---- sharded database, batched and device-resident (BASELINE.json config 4) ---------------------------------------
+// One call per half and batch, so a rank's host enqueues a batch of 8 frames with three calls instead of ~40: the
+// contexts of a batch share ONE stream and one shard (as for reloc_tick_batch_dev), and the exchange between the halves
+// (RCCL all-gather of the rows written here) is enqueued on that same stream by the caller.
+static int shard_batch_check(reloc_ctx *const *ctxs, int n, const char *what)
+{
+    ARG_CHECK(ctxs && n >= 1 && n <= 8, what);
+    for (int f = 0; f < n; ++f) {
+        reloc_ctx *c = ctxs[f];
+        ARG_CHECK(c, "shard batch: NULL context");
+        if (!db_ready(c)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
+        if (c->stream != ctxs[0]->stream || c->device != ctxs[0]->device || c->db_desc != ctxs[0]->db_desc ||
+            c->db_records != ctxs[0]->db_records || c->max_feat != ctxs[0]->max_feat ||
+            memcmp(&c->prm, &ctxs[0]->prm, sizeof(reloc_params)) != 0 || memcmp(c->K4, ctxs[0]->K4, sizeof(c->K4)) != 0 ||
+            memcmp(c->b2c_t, ctxs[0]->b2c_t, sizeof(c->b2c_t)) != 0 || memcmp(c->b2c_R, ctxs[0]->b2c_R, sizeof(c->b2c_R)) != 0) {
+            reloc_set_error("shard batch: the contexts must share one stream (reloc_set_stream), one device and one database "
+                            "(reloc_db_share) and have equal feature capacity, matcher parameters and camera");
+            return RELOC_E_STATE;
+        }
+        for (int g = 0; g < f; ++g) ARG_CHECK(ctxs[g] != c, "shard batch: a context appears twice");
+    }
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_shard_scan_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
+                                         const double *base_poses, int k, int64_t id_base, int32_t *scan_out_dev)
+{
+    int rc = shard_batch_check(ctxs, n, "reloc_shard_scan_batch_dev");
+    if (rc) return rc;
+    ARG_CHECK(imgs_dev && scan_out_dev && k > 0 && k <= MAX_CAND && w >= 64 && h >= 64 && id_base >= 0 &&
+              id_base + ctxs[0]->db_records <= 0x7fffffff, "reloc_shard_scan_batch_dev");
+    (void)hipSetDevice(ctxs[0]->device);
+    double q[8 * 4];
+    for (int f = 0; f < n; ++f) {
+        ARG_CHECK(imgs_dev[f], "reloc_shard_scan_batch_dev: NULL frame");
+        for (int j = 0; j < 4; ++j) q[4 * f + j] = base_poses ? base_poses[7 * f + 3 + j] : (j == 3 ? 1.0 : 0.0);
+    }
+    if ((rc = orb_run_batch_dev(ctxs, n, imgs_dev, w, h, w * 3, order, ctxs[0]->prm.nfeatures))) return rc;
+    reloc_prof_begin(ctxs[0], RELOC_PROF_DB_SCAN);
+    rc = launch_db_scan_batch(ctxs, n, q, heading_cos_tol_host(ctxs[0]), false, base_poses != nullptr);
+    reloc_prof_end(ctxs[0], RELOC_PROF_DB_SCAN);
+    if (rc) return rc;
+    launch_topk_counts_batch(ctxs, n, k, false, (int)id_base, scan_out_dev);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+// The merge every rank performs on the gathered lists (G:342-343 over the whole database): per frame the k best
+// (count desc, global id desc) of the W x k entries, by rank counting -- keys are unique.  One block per frame.
+__global__ __launch_bounds__(256) void k_shard_merge(const int32_t *__restrict__ all_scan, int world, int stride_w, int k, int id_base,
+                                                     int n_local, int32_t *__restrict__ win_gid, int32_t *__restrict__ cand_local,
+                                                     int32_t *__restrict__ n_feat)
+{
+    RELOC_SMALL_KERNEL_PRIO();
+    extern __shared__ unsigned long long s_key[];               // world * k
+    const int f = blockIdx.x, row = 2 * k + 2, E = world * k;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const int32_t *r = all_scan + (size_t)(e / k) * stride_w + (size_t)f * row;
+        const int gid = r[e % k], cnt = r[k + e % k];
+        s_key[e] = gid >= 0 ? ((unsigned long long)(unsigned)cnt << 32) | (unsigned)(gid + 1) : 0ull;
+    }
+    if ((int)threadIdx.x < k) { win_gid[f * k + threadIdx.x] = -1; cand_local[f * k + threadIdx.x] = -1; }
+    if (threadIdx.x == 0) {
+        int m = -1;
+        for (int wv = 0; wv < world; ++wv) m = max(m, all_scan[(size_t)wv * stride_w + (size_t)f * row + 2 * k]);
+        n_feat[f] = m;                                          // ranks without records report -1
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const unsigned long long mine = s_key[e];
+        if (!mine) continue;
+        int rank = 0;
+        for (int j = 0; j < E; ++j) rank += s_key[j] > mine;
+        if (rank < k) {
+            const int gid = (int)(unsigned)(mine & 0xFFFFFFFFu) - 1;
+            win_gid[f * k + rank] = gid;
+            cand_local[f * k + rank] = gid >= id_base && gid < id_base + n_local ? gid - id_base : -1;
+        }
+    }
+}
+
+RELOC_API int reloc_shard_merge_dev(reloc_ctx *ctx, const int32_t *all_scan_dev, int world, int64_t stride_rank, int n, int k,
+                                    int64_t id_base, int64_t n_local, int32_t *win_gid_dev, int32_t *cand_local_dev,
+                                    int32_t *n_feat_dev)
+{
+    ARG_CHECK_CTX(ctx, all_scan_dev && win_gid_dev && cand_local_dev && n_feat_dev && world >= 1 && n >= 1 && n <= 8 && k > 0 &&
+                  k <= MAX_CAND && stride_rank >= (int64_t)n * (2 * k + 2) && id_base >= 0 && n_local >= 0 &&
+                  id_base + n_local <= 0x7fffffff && (int64_t)world * k <= 4096, "reloc_shard_merge_dev");
+    hipLaunchKernelGGL(k_shard_merge, dim3(n), dim3(256), (size_t)world * k * sizeof(unsigned long long), ctx->stream, all_scan_dev, world,
+                       (int)stride_rank, k, (int)id_base, (int)n_local, win_gid_dev, cand_local_dev, n_feat_dev);
+    HIP_TRY(hipGetLastError());
+    return RELOC_OK;
+}
+
+RELOC_API int reloc_shard_solve_batch_dev(reloc_ctx *const *ctxs, int n, const int32_t *cand_local_dev, int k,
+                                          const double *base_poses, const uint64_t *seeds, void *res_out)
+{
+    int rc = shard_batch_check(ctxs, n, "reloc_shard_solve_batch_dev");
+    if (rc) return rc;
+    ARG_CHECK(cand_local_dev && base_poses && res_out && k > 0 && k <= MAX_CAND, "reloc_shard_solve_batch_dev");
+    (void)hipSetDevice(ctxs[0]->device);
+    SetCandBatch sb;
+    for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
+        reloc_ctx *c = ctxs[f < n ? f : 0];
+        sb.cand_ids[f] = c->cand_ids; sb.cand_n[f] = c->cand_n; sb.flags[f] = c->tick_flags;
+    }
+    // candidates of a whole-database search: relocation gates (flag 1), no consistency check
+    hipLaunchKernelGGL(k_set_candidates_batch, dim3(n), dim3(64), 0, ctxs[0]->stream, cand_local_dev, k, sb, 1);
+    return tick_solve_batch(ctxs, n, base_poses, RELOC_TICK_GLOBAL, 0, seeds, (TickResult *)res_out);
 }
 
 // read back the per-candidate PnP records of the last tick (parity taps for tests)

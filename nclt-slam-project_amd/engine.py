@@ -18,6 +18,21 @@ OUTCOME_NAMES = {0: "published", 1: "curr_no_features", 2: "no_candidates", 3: "
                  4: "consistency_fail"}
 
 
+class _PinnedBlock:
+    """one hipHostMalloc allocation, freed with its last reference"""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        if self._ptr:
+            try:
+                self._lib.reloc_host_free(C.c_void_p(self._ptr))
+            except Exception:          # interpreter shutdown
+                pass
+            self._ptr = None
+
+
 class Engine:
     def __init__(self, device: int = 0, max_w: int = 1280, max_h: int = 720, max_feat: int = 8192):
         self._lib = N.load()
@@ -32,9 +47,6 @@ class Engine:
         if getattr(self, "_ctx", None):
             self._lib.reloc_destroy(self._ctx)
             self._ctx = None
-            for p in getattr(self, "_pinned", []):
-                self._lib.reloc_host_free(C.c_void_p(p))
-            self._pinned = []
 
     def __del__(self):
         try:
@@ -80,17 +92,18 @@ class Engine:
         N.check(self._lib.reloc_d2h(self._ctx, N.ptr(dst), C.c_void_p(src_dev), dst.nbytes), "reloc_d2h")
 
     def pinned(self, shape, dtype=np.uint8) -> np.ndarray:
-        """numpy array over page-locked host memory (hipHostMalloc): H2D / D2H copies from it are asynchronous DMA"""
+        """numpy array over page-locked host memory (hipHostMalloc): H2D / D2H copies from it are asynchronous DMA.
+        The memory belongs to the ARRAY, not to this engine: it is released when the last view of it is collected (closing
+        an engine frees nothing that another engine's ticks may still write).  Keep the array alive until every
+        context told to write into it (tick_result_to) has been synchronised or pointed elsewhere."""
         dt = np.dtype(dtype)
         n = int(np.prod(shape)) * dt.itemsize
         p = self._lib.reloc_host_alloc(n)
         if not p:
             raise N.RelocError("reloc_host_alloc failed: " + N.last_error())
         buf = (C.c_uint8 * max(n, 1)).from_address(p)
-        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(p)
-        return arr
+        buf._owner = _PinnedBlock(self._lib, p)               # the views' base chain ends in `buf`, which holds the block
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
     @property
     def stream_ptr(self) -> int:
@@ -346,6 +359,11 @@ class Engine:
         N.check(self._lib.reloc_get_params(self._ctx, C.byref(p)), "reloc_get_params")
         return p
 
+    def set_params_from(self, other: "Engine"):
+        """copy another engine's matcher parameters (the contexts of a batch must carry equal ones)"""
+        p = other.get_params()
+        N.check(self._lib.reloc_set_params(self._ctx, C.byref(p)), "reloc_set_params")
+
     def set_params(self, **kw):
         """matcher parameters of the fused tick (reloc_params in include/reloc.h); unnamed fields keep their value"""
         p = self.get_params()
@@ -409,6 +427,37 @@ class Engine:
         lib = engines[0]._lib
         N.check(lib.reloc_tick_batch_dev(ctxs, n, imgs, w, h, int(order_rgb), N.ptr(bp), int(global_reloc), N.ptr(sd)),
                 "reloc_tick_batch_dev")
+
+    # ---- sharded database, batched halves with the exchange in device memory (reloc_shard_*_dev) ----
+    @staticmethod
+    def shard_scan_batch_dev(engines, imgs_dev, w: int, h: int, base_poses, k: int, id_base: int, scan_out_dev: int, order_rgb=False):
+        """ORB per frame + ONE scan launch + per-frame ranking for n <= 8 engines that share a stream and a shard; row f of
+        scan_out_dev (2k + 2 int32) = k global ids, k counts, feature count, 0.  Enqueue only."""
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e._ctx for e in engines])
+        imgs = (C.c_void_p * n)(*[int(p) for p in imgs_dev])
+        bp = None if base_poses is None else np.ascontiguousarray(base_poses, np.float64).reshape(n, 7)
+        lib = engines[0]._lib
+        N.check(lib.reloc_shard_scan_batch_dev(ctxs, n, imgs, int(w), int(h), int(order_rgb), N.ptr(bp), int(k), int(id_base),
+                                               C.c_void_p(scan_out_dev)), "reloc_shard_scan_batch_dev")
+
+    def shard_merge_dev(self, all_scan_dev: int, world: int, stride_rank: int, n: int, k: int, id_base: int, n_local: int,
+                        win_gid_dev: int, cand_local_dev: int, n_feat_dev: int):
+        """the merge every rank performs on the gathered rows, on this engine's stream (enqueue only)"""
+        N.check(self._lib.reloc_shard_merge_dev(self._ctx, C.c_void_p(all_scan_dev), int(world), int(stride_rank), int(n), int(k),
+                                                int(id_base), int(n_local), C.c_void_p(win_gid_dev), C.c_void_p(cand_local_dev),
+                                                C.c_void_p(n_feat_dev)), "reloc_shard_merge_dev")
+
+    @staticmethod
+    def shard_solve_batch_dev(engines, cand_local_dev: int, k: int, base_poses, seeds, res_out: int):
+        """matches + PnP + gates for the owned winners of every frame; result record f stored at res_out + 96 f (device
+        or pinned host memory).  Enqueue only."""
+        n = len(engines)
+        ctxs = (C.c_void_p * n)(*[e._ctx for e in engines])
+        bp = np.ascontiguousarray(base_poses, np.float64).reshape(n, 7)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64).reshape(n)
+        N.check(engines[0]._lib.reloc_shard_solve_batch_dev(ctxs, n, C.c_void_p(cand_local_dev), int(k), N.ptr(bp), N.ptr(sd),
+                                                            C.c_void_p(res_out)), "reloc_shard_solve_batch_dev")
 
     def tick_scan_enqueue(self, img_dev: int, w: int, h: int, base_pose=None, k: int = 25, order_rgb=False):
         """ORB + whole-shard scan + local top-k, enqueued on the ctx stream; read with tick_scan_fetch(k)."""

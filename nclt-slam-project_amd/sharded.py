@@ -23,7 +23,7 @@ import numpy as np
 from .landmarks import shard_by_rows
 
 K_GLOBAL = 25
-MIN_FEATURES = 10      # MIN_MATCHES: fewer current keypoints -> curr_no_features (M:307)
+MIN_FEATURES = 10      # MIN_MATCHES default: fewer current keypoints -> curr_no_features (M:307); engines carry their own
 
 
 def merge_topk(all_ids, all_counts, k=K_GLOBAL):
@@ -54,6 +54,9 @@ class ShardedRelocalizer:
 
     def __init__(self, backend, shard_base: int, rank: int = 0, world: int = 1, group=None, device=None):
         self.backend, self.base, self.rank, self.world, self.group, self.device = backend, int(shard_base), rank, world, group, device
+        # curr_no_features gate (M:307): the matcher parameter of the shard's engine when there is one
+        eng = getattr(backend, "engine", None)
+        self.min_features = int(eng.get_params().min_matches) if eng is not None and hasattr(eng, "get_params") else MIN_FEATURES
 
     def _all_gather(self, arr: np.ndarray) -> np.ndarray:
         if self.world == 1:
@@ -89,12 +92,12 @@ class ShardedRelocalizer:
             lids, cnts = scan[0], scan[1]
             packed[i, :k] = np.where(lids >= 0, lids + self.base, -1)
             packed[i, k:2 * k] = cnts
-            packed[i, 2 * k] = scan[2] if len(scan) > 2 else MIN_FEATURES
+            packed[i, 2 * k] = scan[2] if len(scan) > 2 else self.min_features
         allp = self._all_gather(packed)                                       # (world, B, 2k + 1)
         n_feat = allp[:, :, 2 * k].max(axis=0)
         winners, jobs = [], []
         for i in range(B):
-            if n_feat[i] < MIN_FEATURES:
+            if n_feat[i] < self.min_features:
                 winners.append((np.zeros(0, np.int64), []))
                 continue
             win_ids, _ = merge_topk(allp[:, i, :k], allp[:, i, k:2 * k], k)
@@ -109,7 +112,7 @@ class ShardedRelocalizer:
         res = np.zeros((B, 12), np.float64)                                   # [pos, n_inl, reproj, outcome, gid, pose7]
         for i in range(B):
             res[i, 0] = 1e9
-            res[i, 3] = 1 if n_feat[i] < MIN_FEATURES else (3 if len(winners[i][0]) else 2)
+            res[i, 3] = 1 if n_feat[i] < self.min_features else (3 if len(winners[i][0]) else 2)
         for (i, _), r in zip(jobs, solved):
             mine = winners[i][1]
             if r["outcome"] in (0, 4):
@@ -242,76 +245,160 @@ def pick_results(res_all: np.ndarray, win_gid: np.ndarray, n_feat: np.ndarray, b
     return out
 
 
-class DeviceShardedRelocalizer:
-    """tick_batch of ShardedRelocalizer with the exchange on the device.  shard: HipShard with >= B slots; device: the
-    torch device of this rank; group / world as for torch.distributed (world 1: no collective)."""
+class _Batch:
+    """one batch in flight on a group's stream (DeviceShardedRelocalizer.submit)"""
+    __slots__ = ("group", "n", "done")
 
-    def __init__(self, shard: "HipShard", rank: int, world: int, device, group=None, k: int = K_GLOBAL, bases=None):
+    def __init__(self, group, n):
+        self.group, self.n, self.done = group, n, False
+
+
+class DeviceShardedRelocalizer:
+    """tick_batch of ShardedRelocalizer with the exchange on the device and several batches in flight.
+
+    A *group* = `batch` contexts that share ONE stream and the rank's shard (reloc_db_share), plus the group's exchange
+    buffers.  A batch is three library calls and two collectives, all enqueued on the group's stream, nothing waited for:
+        reloc_shard_scan_batch_dev   ORB per frame, ONE scan launch for the batch, per-frame ranking -> rows of global ids
+        all-gather                   B x (2k + 2) int32 per rank (RCCL over xGMI; nothing at world 1)
+        reloc_shard_merge_dev        identical merge on every rank -> winners, the ones this rank owns
+        reloc_shard_solve_batch_dev  owners solve; result records stored straight into the gather buffer
+        all-gather                   B x 96 bytes per rank
+        one copy of (results, winners, feature counts) into pinned host memory, then an event
+    `depth` groups take batches round-robin, so the scan of batch i + 1 is on the device before the exchange of batch i
+    has finished (round 2 ran one batch at a time with three host synchronisations in it and per-frame launches: half
+    the unsharded rate at equal records per rank).  submit() enqueues, result() waits for that batch's event only.
+
+    group: None -> torch.distributed default group; an object with all_gather_tensor(rank, out, inp, stream) stands in for
+    it when the ranks are threads of one process (tests)."""
+
+    def __init__(self, shard: "HipShard", rank: int, world: int, device, group=None, k: int = K_GLOBAL, bases=None,
+                 batch: int | None = None, depth: int = 2, n_streams: int = 4):
         import torch
+        from .engine import Engine
         self.torch, self.shard, self.rank, self.world, self.device, self.group, self.k = torch, shard, rank, world, device, group, k
-        B = len(shard.engines)
-        self.B = B
-        self.scan_buf = torch.full((B, 2 * k + 2), -1, dtype=torch.int32, device=device)
-        self.res_buf = torch.zeros((B, 96), dtype=torch.uint8, device=device)
-        self.all_scan = torch.empty((world, B, 2 * k + 2), dtype=torch.int32, device=device)
-        self.all_res = torch.empty((world, B, 96), dtype=torch.uint8, device=device)
-        self.exch = torch.cuda.Stream(device=device)
-        self.ext = [torch.cuda.ExternalStream(e.stream_ptr, device=device) for e in shard.engines]
+        B = batch if batch is not None else max(1, min(8, len(shard.engines)))
+        self.B, self.depth = B, depth
+        e0 = shard.engine
+        self.min_features = int(e0.get_params().min_matches) if shard.n_records else MIN_FEATURES
+        row = 2 * k + 2
+        self.groups = []
+        # the groups' streams are made first and one after the other: the HIP runtime hands a new stream the least-used of
+        # its (four) hardware queues, and two groups whose streams share a hardware queue run strictly one after the other
+        # (four hardware queues: more than four streams only share them; further groups take turns on the four streams, which
+        # is what lets the host run `depth` batches ahead of the device)
+        streams = [torch.cuda.Stream(device=device) for _ in range(min(depth, n_streams))]
+        for g in range(depth):
+            ts = streams[g % len(streams)]
+            engines = []
+            if shard.n_records:
+                for _ in range(B):
+                    e = Engine(e0.device, e0.max_w, e0.max_h, e0.max_feat)
+                    e.db_share(e0)
+                    e.set_params_from(e0)
+                    e.set_stream(ts.cuda_stream)
+                    engines.append(e)
+            self.groups.append(dict(
+                stream=ts, engines=engines,
+                scan=torch.full((B, row), -1, dtype=torch.int32, device=device),
+                all_scan=torch.empty((world, B, row), dtype=torch.int32, device=device),
+                win_gid=torch.empty((B, k), dtype=torch.int32, device=device),
+                cand_local=torch.empty((B, k), dtype=torch.int32, device=device),
+                n_feat=torch.empty((B,), dtype=torch.int32, device=device),
+                res=torch.zeros((B, 96), dtype=torch.uint8, device=device),
+                all_res=torch.empty((world, B, 96), dtype=torch.uint8, device=device),
+                h_res=torch.empty((world, B, 96), dtype=torch.uint8).pin_memory(),
+                h_win=torch.empty((B, k), dtype=torch.int32).pin_memory(),
+                h_nfeat=torch.empty((B,), dtype=torch.int32).pin_memory(),
+                event=torch.cuda.Event(), pending=None))
+        self._next = 0
         if bases is None:
             if world == 1:
                 bases = [shard.base]
             else:
-                import torch.distributed as dist
                 t = torch.tensor([shard.base], dtype=torch.int64, device=device)
                 allb = torch.empty(world, dtype=torch.int64, device=device)
-                dist.all_gather_into_tensor(allb, t, group=group)
+                self._all_gather(allb, t, torch.cuda.current_stream(device))
                 bases = allb.cpu().tolist()
         self.bases = list(bases)
 
-    def tick_batch(self, frames_dev, base_poses, seeds=None):
-        torch, sh, k, B = self.torch, self.shard, self.k, len(frames_dev)
-        if B > self.B:
-            raise ValueError(f"batch of {B} frames on a shard with {self.B} slots")
-        seeds = list(seeds) if seeds is not None else [0] * B
-        es = sh.engines
-        sb = self.scan_buf
-        row = sb.stride(0) * 4
-        if sh.n_records:
-            for i in range(B):                                        # ORB + shard scan + local top-k, one stream per frame
-                p = sb.data_ptr() + i * row
-                es[i].tick_scan_into(frames_dev[i], sh.w, sh.h, base_poses[i], k, p, p + 4 * k, p + 8 * k)
-        with torch.cuda.stream(self.exch):
-            for i in range(B):
-                self.exch.wait_stream(self.ext[i])
+    def _all_gather(self, out, inp, stream):
+        """out (world, ...) <- inp of every rank, ordered on `stream`"""
+        if self.world == 1:
+            out[0].copy_(inp)
+        elif hasattr(self.group, "all_gather_tensor"):
+            self.group.all_gather_tensor(self.rank, out, inp, stream)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out, inp, group=self.group)    # stream-ordered against the current stream
+
+    def submit(self, frames_dev, base_poses, seeds=None) -> _Batch:
+        """enqueue one batch (<= `batch` frames) on the next group's stream; nothing is waited for unless that group's
+        previous batch has not been collected yet"""
+        torch, sh, k, n = self.torch, self.shard, self.k, len(frames_dev)
+        if n > self.B or n < 1:
+            raise ValueError(f"batch of {n} frames on groups of {self.B} slots")
+        g = self.groups[self._next]
+        self._next = (self._next + 1) % self.depth
+        if g["pending"] is not None and not g["pending"].done:
+            g["event"].synchronize()                              # its buffers are still in use
+            g["pending"].done = True
+        from .engine import Engine
+        seeds = list(seeds) if seeds is not None else [0] * n
+        row = 2 * k + 2
+        with torch.cuda.stream(g["stream"]):
             if sh.n_records:
-                ids = sb[:, :k]
-                sb[:, :k] = torch.where(ids >= 0, ids + sh.base, ids)              # local -> global ids
-            else:
-                sb[:, :k] = -1; sb[:, k:2 * k] = 0; sb[:, 2 * k] = -1
+                Engine.shard_scan_batch_dev(g["engines"][:n], frames_dev, sh.w, sh.h, base_poses, k, sh.base, g["scan"].data_ptr())
+            else:                                                 # more ranks than records: this rank only takes part in the exchange
+                g["scan"][:, :k] = -1; g["scan"][:, k:2 * k] = 0; g["scan"][:, 2 * k] = -1
             if self.world > 1:
-                import torch.distributed as dist
-                dist.all_gather_into_tensor(self.all_scan, sb, group=self.group)  # B x (2k + 2) ints per rank
-                all_scan = self.all_scan
+                self._all_gather(g["all_scan"], g["scan"], g["stream"])
+                all_scan, stride = g["all_scan"], self.B * row
             else:
-                all_scan = sb[None]
-            win_gid, cand_local, n_feat = merge_topk_tensor(all_scan[:, :B], k, sh.base, sh.n_records)
-        if sh.n_records:
-            for i in range(B):                                        # owners solve; a rank without a winner finishes at once
-                self.ext[i].wait_stream(self.exch)
-                es[i].tick_solve_from(cand_local.data_ptr() + i * k * 4, k, base_poses[i], False, seeds[i])
-                es[i].d2d(self.res_buf.data_ptr() + i * 96, es[i].tick_result_dev, 96)
-        with torch.cuda.stream(self.exch):
-            for i in range(B):
-                self.exch.wait_stream(self.ext[i])
-            if not sh.n_records:
-                self.res_buf.zero_()
-                self.res_buf.view(torch.int32)[:, 18] = 2             # outcome no_candidates, never picked
+                all_scan, stride = g["scan"], self.B * row
+            eng = g["engines"][0] if sh.n_records else None
+            if eng is not None:
+                eng.shard_merge_dev(all_scan.data_ptr(), self.world, stride, n, k, sh.base, sh.n_records, g["win_gid"].data_ptr(),
+                                    g["cand_local"].data_ptr(), g["n_feat"].data_ptr())
+                res = g["all_res"][self.rank] if self.world > 1 else g["res"]
+                Engine.shard_solve_batch_dev(g["engines"][:n], g["cand_local"].data_ptr(), k, base_poses, seeds, res.data_ptr())
+            else:
+                wg, _, nf = merge_topk_tensor(all_scan.view(self.world, self.B, row)[:, :n], k, sh.base, 0)
+                g["win_gid"][:n] = wg; g["n_feat"][:n] = nf
+                res = g["all_res"][self.rank] if self.world > 1 else g["res"]
+                res.zero_()
+                res.view(torch.int32)[:, 18] = 2                  # outcome no_candidates, never picked
             if self.world > 1:
-                import torch.distributed as dist
-                dist.all_gather_into_tensor(self.all_res, self.res_buf, group=self.group)
-                all_res = self.all_res
+                # in place: every rank's own records already sit in its slice of all_res
+                self._all_gather(g["all_res"], g["all_res"][self.rank].clone(), g["stream"])
+                all_res = g["all_res"]
             else:
-                all_res = self.res_buf[None]
-            host = (all_res[:, :B].cpu().numpy(), win_gid.cpu().numpy(), n_feat.cpu().numpy())   # the one trip to the host
-        self._keep = (cand_local, win_gid)                            # alive until the streams have passed them
-        return pick_results(host[0], host[1], host[2], self.bases)
+                all_res = g["res"][None]
+            g["h_res"][:all_res.shape[0]].copy_(all_res, non_blocking=True)       # the one trip to the host, not waited for here
+            g["h_win"].copy_(g["win_gid"], non_blocking=True)
+            g["h_nfeat"].copy_(g["n_feat"], non_blocking=True)
+            g["event"].record(g["stream"])
+        b = _Batch(g, n)
+        g["pending"] = b
+        return b
+
+    def result(self, b: _Batch):
+        """wait for that batch (its event only) and pick every frame's anchor"""
+        g = b.group
+        if g["pending"] is not b:
+            raise RuntimeError("this batch's buffers have been reused: collect a batch before `depth` more are submitted")
+        g["event"].synchronize()
+        b.done = True
+        n = b.n
+        return pick_results(np.ascontiguousarray(g["h_res"].numpy()[:self.world, :n]), g["h_win"].numpy()[:n].copy(),
+                            g["h_nfeat"].numpy()[:n].copy(), self.bases, self.min_features)
+
+    def tick_batch(self, frames_dev, base_poses, seeds=None):
+        return self.result(self.submit(frames_dev, base_poses, seeds))
+
+    def close(self):
+        for g in self.groups:
+            g["event"].synchronize() if g["pending"] is not None else None
+            g["stream"].synchronize()
+            for e in g["engines"]:
+                e.close()
+            g["engines"] = []

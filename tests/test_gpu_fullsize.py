@@ -146,23 +146,41 @@ def test_config4_batch_of_8_on_100k_records(engine, oracle, config4):
     assert counts[top[0]] == counts.max() and len(top) >= 1
 
 
+def _assert_batch(res, ref):
+    for got, (exp, dbg) in zip(res, ref):
+        assert got["outcome"] == exp["outcome"] and got["n_inliers"] == exp["n_inliers"] and got["lm_idx"] == exp["lm_idx"]
+        assert got["n_candidates"] == exp["n_candidates"]
+        np.testing.assert_allclose(got["anchor_pose"], exp["anchor_pose"], atol=1e-9)
+
+
 def test_config4_device_resident_exchange(engine, config4):
-    """the same 8-frame batch with the exchange kept on the device (DeviceShardedRelocalizer: scan results written into
-    a torch buffer, global ids / merge / candidate hand-over by tiny torch ops, owners solve from device-resident lists,
-    result records gathered on the device, ONE copy to the host per batch) == the unsharded tick"""
+    """the same 8-frame batch with the exchange kept on the device (DeviceShardedRelocalizer: three library calls per
+    batch -- scan half with ONE scan launch, merge, solve half -- on the group's stream, result records stored straight
+    into the gather buffer, ONE copy to the host per batch) == the unsharded tick; also with three batches in flight
+    and with a short batch, so buffers, streams and ticket counters are reused in every order"""
     import torch
     from nclt_slam_project_amd.sharded import DeviceShardedRelocalizer, HipShard
     frames, db, base_poses, ref = config4
     desc, pts, off, poses = db
-    shard = HipShard(engine, desc, pts, off, poses, rank=0, world=1, n_slots=8)
-    sr = DeviceShardedRelocalizer(shard, 0, 1, torch.device("cuda", 0))
+    shard = HipShard(engine, desc, pts, off, poses, rank=0, world=1)
+    sr = DeviceShardedRelocalizer(shard, 0, 1, torch.device("cuda", 0), batch=8, depth=3)
     fdev = [engine.to_device(f) for f in frames]
-    for rep in range(2):                                  # twice: buffers and streams are reused between batches
-        res = sr.tick_batch(fdev, base_poses, seeds=[100 + f for f in range(8)])
-        for got, (exp, dbg) in zip(res, ref):
-            assert got["outcome"] == exp["outcome"] and got["n_inliers"] == exp["n_inliers"] and got["lm_idx"] == exp["lm_idx"]
-            assert got["n_candidates"] == exp["n_candidates"]
-            np.testing.assert_allclose(got["anchor_pose"], exp["anchor_pose"], atol=1e-9)
+    seeds = [100 + f for f in range(8)]
+    for rep in range(2):                                  # synchronous form
+        _assert_batch(sr.tick_batch(fdev, base_poses, seeds=seeds), ref)
+    flight = [sr.submit(fdev, base_poses, seeds) for _ in range(3)]          # pipelined: nothing waited for between them
+    for b in flight:
+        _assert_batch(sr.result(b), ref)
+    short = sr.submit(fdev[2:5], base_poses[2:5], seeds[2:5])
+    full = sr.submit(fdev, base_poses, seeds)
+    _assert_batch(sr.result(short), ref[2:5])
+    _assert_batch(sr.result(full), ref)
+    with pytest.raises(RuntimeError):                     # a batch whose buffers were reused says so instead of returning another batch's records
+        stale = sr.submit(fdev, base_poses, seeds)
+        for _ in range(3):
+            sr.submit(fdev, base_poses, seeds)
+        sr.result(stale)
+    sr.close()
     for p in fdev:
         engine.dev_free(p)
     shard.close()
@@ -261,6 +279,70 @@ def test_config4_eight_shards_through_the_real_merge(engine, config4):
         if exp["outcome"] == 0:
             owners.add(int(exp["lm_idx"]) * world // 100000)
     assert len(owners) >= 3                       # winners live on several different shards
+
+
+class _InProcessDeviceGroup:
+    """the collective seam of DeviceShardedRelocalizer when the ranks are threads on one GPU: an all-gather of device
+    tensors made of a barrier and device copies (RCCL needs one process per GPU; the exchange code around it is the same)"""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+
+    def all_gather_tensor(self, rank, out, inp, stream):
+        import torch
+        stream.synchronize()                               # this rank's contribution is complete
+        self.slots[rank] = inp
+        self.barrier.wait()
+        with torch.cuda.stream(stream):
+            for r in range(self.world):
+                out[r].copy_(self.slots[r])
+        stream.synchronize()                               # everybody has read before anybody overwrites
+        self.barrier.wait()
+
+
+def test_config4_eight_shards_device_exchange(engine, config4):
+    """world = 8 through the DEVICE-resident exchange: 8 record shards as 8 threads on the one GPU,
+    every rank runs DeviceShardedRelocalizer -- batched scan half, the all_gather_into_tensor seam, reloc_shard_merge_dev
+    over 8 x 25 entries per frame, owners solve into their slice of the gather buffer, second all-gather, pick_results --
+    with two batches in flight: every rank returns what the unsharded tick returns"""
+    import threading
+    import torch
+    from nclt_slam_project_amd.engine import Engine
+    from nclt_slam_project_amd.sharded import DeviceShardedRelocalizer, HipShard
+    frames, db, base_poses, ref = config4
+    desc, pts, off, poses = db
+    world = 8
+    group = _InProcessDeviceGroup(world)
+    results, errors = [None] * world, []
+    bases = [int(b) for b in __import__("nclt_slam_project_amd.landmarks", fromlist=["x"]).shard_by_rows(off, world)[:world]]
+    seeds = [100 + f for f in range(8)]
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            e = Engine(0, 640, 480, 2048)
+            shard = HipShard(e, desc, pts, off, poses, rank=rank, world=world)
+            sr = DeviceShardedRelocalizer(shard, rank, world, torch.device("cuda", 0), group=group, bases=bases, batch=8, depth=2)
+            fdev = [e.to_device(f) for f in frames]
+            a = sr.submit(fdev, base_poses, seeds)
+            b = sr.submit(fdev[:5], base_poses[:5], seeds[:5])
+            results[rank] = (sr.result(a), sr.result(b))
+            sr.close()
+            e.close()
+        except Exception as ex:           # a rank that dies would leave the others in the barrier
+            errors.append(ex)
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for rank in range(world):
+        _assert_batch(results[rank][0], ref)
+        _assert_batch(results[rank][1], ref[:5])
 
 
 @pytest.mark.parametrize("records,w,h", [(1000, 640, 480), (10000, 1280, 720)])
