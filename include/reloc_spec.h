@@ -27,11 +27,20 @@
  * (decided from the score histogram alone, so the rule is order-independent). */
 #define RELOC_ORB_STAGE1_CAP     4096
 
-/* BGR->gray 8-bit fixed point: Y = (B*1868 + G*9617 + R*4899 + 8192) >> 14 */
+/* BGR->gray 8-bit fixed point.  Two published OpenCV conventions, chosen by reloc_params.gray_coeff_bits:
+ *   14 (default; OpenCV <= 3.x, `yuv_shift`): Y = (B*1868 + G*9617 + R*4899 + 8192)  >> 14
+ *   15 (OpenCV 4.x 8-bit path, `gray_shift`):                Y = (B*3735 + G*19235 + R*9798 + 16384) >> 15
+ * They differ by +-1 on some pixels.  Neither can be checked against OpenCV offline (parity unpinned). */
 #define RELOC_GRAY_CB            1868
 #define RELOC_GRAY_CG            9617
 #define RELOC_GRAY_CR            4899
 #define RELOC_GRAY_SHIFT         14
+#define RELOC_GRAY15_CB          3735
+#define RELOC_GRAY15_CG          19235
+#define RELOC_GRAY15_CR          9798
+#define RELOC_GRAY15_SHIFT       15
+/* order argument of the gray stage: bit 0 = channel order (RELOC_ORDER_RGB), bit 1 = the 15-bit coefficient set */
+#define RELOC_GRAY_FLAG_15BIT    2
 
 /* 7x7 sigma=2 Gaussian in 8 fractional bits, sum == 256.  Horizontal pass in
  * 8.8 fixed point, vertical pass in 16.16, result = (v + 32768) >> 16, BORDER_REFLECT_101. */

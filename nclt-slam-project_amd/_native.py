@@ -94,7 +94,7 @@ class RelocParams(C.Structure):
                 ("accum_min_kpts", i32), ("candidate_radius_m", f64), ("heading_tol_deg", f64), ("reproj_max_px", f64),
                 ("ransac_reproj_px", f64), ("ransac_confidence", f64), ("consistency_m", f64),
                 ("global_reproj_max_px", f64), ("accum_min_dist_m", f64), ("accum_depth_min_m", f64),
-                ("accum_depth_max_m", f64)]
+                ("accum_depth_max_m", f64), ("gray_coeff_bits", i32), ("reserved0", i32)]
 
 
 _lib = None

@@ -142,6 +142,8 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_min_dist_m = RELOC_ACCUM_MIN_DIST_M;
     c->prm.accum_depth_min_m = RELOC_ACCUM_DEPTH_MIN_M;
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
+    c->prm.gray_coeff_bits = RELOC_GRAY_SHIFT;
+    c->prm.reserved0 = 0;
     if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
     if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
     if (const char *e = getenv("RELOC_SCAN_NW")) c->scan_nw = atoi(e);
@@ -209,6 +211,8 @@ RELOC_API int reloc_set_params(reloc_ctx *c, const reloc_params *p)
     ARG_CHECK(p->candidate_radius_m >= 0 && p->heading_tol_deg >= 0 && p->heading_tol_deg <= 180 && p->ransac_reproj_px > 0 &&
                   p->ransac_confidence > 0 && p->ransac_confidence < 1 && p->consistency_m >= 0 && p->accum_min_dist_m >= 0,
               "a gate is out of range");
+    ARG_CHECK((p->gray_coeff_bits == RELOC_GRAY_SHIFT || p->gray_coeff_bits == RELOC_GRAY15_SHIFT) && p->reserved0 == 0,
+              "gray_coeff_bits must be 14 or 15, reserved0 must be 0");
     c->prm = *p;
     return RELOC_OK;
 }

@@ -67,6 +67,19 @@ __device__ __forceinline__ int reflect101(int p, int n)
 }
 
 // ---- gray ---------------------------------------------------------------------------------------
+// `order_rgb` of the gray stages carries two flags: bit 0 = RELOC_ORDER_RGB, bit 1 = RELOC_GRAY_FLAG_15BIT (the 15-bit
+// coefficient set of reloc_params.gray_coeff_bits == 15).  Both are launch-uniform: the selects run on the scalar unit.
+__device__ __forceinline__ int gray_fixed(int b, int g, int r, int flags)
+{
+    const bool c15 = flags & RELOC_GRAY_FLAG_15BIT;
+    const int cb = c15 ? RELOC_GRAY15_CB : RELOC_GRAY_CB, cg = c15 ? RELOC_GRAY15_CG : RELOC_GRAY_CG, cr = c15 ? RELOC_GRAY15_CR : RELOC_GRAY_CR;
+    const int sh = c15 ? RELOC_GRAY15_SHIFT : RELOC_GRAY_SHIFT;
+    return (b * cb + g * cg + r * cr + (1 << (sh - 1))) >> sh;
+}
+static inline int gray_flags(const reloc_ctx *ctx, int order)
+{
+    return (order & 1) | (ctx->prm.gray_coeff_bits == RELOC_GRAY15_SHIFT ? RELOC_GRAY_FLAG_15BIT : 0);
+}
 // plain gray output for reloc_gray_u8 (dense rows)
 __global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ src, int w, int h, int sstride, int order_rgb,
                                                     uint8_t *__restrict__ dst)
@@ -75,8 +88,8 @@ __global__ __launch_bounds__(256) void k_gray_plain(const uint8_t *__restrict__ 
     if (x >= w) return;
     const uint8_t *s = src + (size_t)y * sstride + 3 * x;
     const int c0 = s[0], c1 = s[1], c2 = s[2];
-    const int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
-    dst[(size_t)y * w + x] = (uint8_t)((b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT);
+    const int b = (order_rgb & 1) ? c2 : c0, r = (order_rgb & 1) ? c0 : c2;
+    dst[(size_t)y * w + x] = (uint8_t)gray_fixed(b, c1, r, order_rgb);
 }
 
 // ---- fused pyramid ------------------------------------------------------------------------------
@@ -137,8 +150,8 @@ __device__ __forceinline__ u32 pyr_gray4(const u32 (&d)[3], int x4, int w, int o
         int c[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { const int bi = 3 * k + j; c[j] = (d[bi >> 2] >> (8 * (bi & 3))) & 0xFF; }
-        const int b = order_rgb ? c[2] : c[0], r = order_rgb ? c[0] : c[2];
-        const int g = (b * RELOC_GRAY_CB + c[1] * RELOC_GRAY_CG + r * RELOC_GRAY_CR + (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT;
+        const int b = (order_rgb & 1) ? c[2] : c[0], r = (order_rgb & 1) ? c[0] : c[2];
+        const int g = gray_fixed(b, c[1], r, order_rgb);
         if (x4 + k < w) out |= (u32)g << (8 * k);
     }
     return out;
@@ -1065,7 +1078,7 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
         for (int l = 0; l < NLEV; ++l) lds.lev[l] = ctx->pyr_lds[l];
         lds.tabs = ctx->pyr_lds[NLEV];
         hipLaunchKernelGGL(wide ? kern512 : kern256, dim3(ctx->pyr_ntiles), dim3(wide ? 512 : 256), ctx->pyr_lds_bytes, st, tab_d,
-                           (const PyrTile *)ctx->pyr_tiles, ctx->rz_tab, src_dev, w, h, stride, order, ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
+                           (const PyrTile *)ctx->pyr_tiles, ctx->rz_tab, src_dev, w, h, stride, gray_flags(ctx, order), ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
     }
     hipLaunchKernelGGL(k_fast_blur, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr,
                        ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV]);
@@ -1092,7 +1105,8 @@ int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_
         if (f < n) {
             const int rc = orb_prepare(c, w, h, nfeatures);
             if (rc) return rc;
-            if (c->pyr_ntiles != ctxs[0]->pyr_ntiles || c->pyr_lds_bytes != ctxs[0]->pyr_lds_bytes || c->max_feat != ctxs[0]->max_feat) {
+            if (c->pyr_ntiles != ctxs[0]->pyr_ntiles || c->pyr_lds_bytes != ctxs[0]->pyr_lds_bytes || c->max_feat != ctxs[0]->max_feat ||
+                c->prm.gray_coeff_bits != ctxs[0]->prm.gray_coeff_bits) {
                 reloc_set_error("orb batch: contexts of unequal geometry");
                 return RELOC_E_STATE;
             }
@@ -1114,9 +1128,9 @@ int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_
     lds.tabs = c0->pyr_lds[NLEV];
     // 256-thread pyramid: a batch runs beside other streams' scans (see orb_run_dev)
     if (aligned)
-        hipLaunchKernelGGL((k_pyramid_batch<3, true, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, order, lds);
+        hipLaunchKernelGGL((k_pyramid_batch<3, true, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, gray_flags(c0, order), lds);
     else
-        hipLaunchKernelGGL((k_pyramid_batch<3, false, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, order, lds);
+        hipLaunchKernelGGL((k_pyramid_batch<3, false, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, gray_flags(c0, order), lds);
     hipLaunchKernelGGL(k_fast_blur_batch, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV], n), dim3(256), 0, st, b,
                        tab_h->fast_tile_base[NLEV]);
     hipLaunchKernelGGL(k_harris_batch, dim3(tab_h->flat_base[NLEV], n), dim3(256), 0, st, b);
@@ -1137,7 +1151,7 @@ RELOC_API int reloc_gray_u8(reloc_ctx *ctx, const uint8_t *img, int w, int h, in
     int rc;
     if ((rc = reloc_scratch(ctx, 0, (int64_t)w * h, &dout))) return rc;
     HIP_TRY(hipMemcpy2DAsync(ctx->frame_img, (size_t)w * 3, img, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_gray_plain, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, ctx->frame_img, w, h, w * 3, order,
+    hipLaunchKernelGGL(k_gray_plain, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, ctx->frame_img, w, h, w * 3, gray_flags(ctx, order),
                        (uint8_t *)dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(gray, dout, (size_t)w * h, hipMemcpyDeviceToHost, ctx->stream));

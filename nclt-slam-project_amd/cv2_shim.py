@@ -151,6 +151,7 @@ class Cv2Shim:
     SOLVEPNP_ITERATIVE = SOLVEPNP_ITERATIVE
     SOLVEPNP_EPNP = SOLVEPNP_EPNP
     SOLVEPNP_P3P = SOLVEPNP_P3P
+    SOLVEPNP_AP3P = SOLVEPNP_AP3P
     error = error
     KeyPoint = KeyPoint
     DMatch = DMatch
@@ -184,6 +185,14 @@ class Cv2Shim:
     def solvePnPRansac(self, objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None,
                        useExtrinsicGuess=False, iterationsCount=100, reprojectionError=8.0, confidence=0.99,
                        inliers=None, flags=SOLVEPNP_ITERATIVE):
+        """All accepted `flags` (ITERATIVE, EPNP, P3P, AP3P -- the reference's history switches between ITERATIVE and EPNP,
+        M:342-348) select the SAME solver: P3P + 1 hypotheses scored by reprojection, Levenberg-Marquardt refinement on the
+        inliers.  Anything this solver would silently ignore raises `error` instead: another flag, an
+        extrinsic guess, lens distortion."""
+        if flags not in (SOLVEPNP_ITERATIVE, SOLVEPNP_EPNP, SOLVEPNP_P3P, SOLVEPNP_AP3P):
+            raise error(f"solvePnPRansac: flags={flags!r} is not implemented (ITERATIVE, EPNP, P3P and AP3P map to one solver)")
+        if useExtrinsicGuess:
+            raise error("solvePnPRansac: useExtrinsicGuess=True is not implemented (the reference never passes a guess)")
         obj = np.asarray(objectPoints, np.float32).reshape(-1, 3)
         img = np.asarray(imagePoints, np.float32).reshape(-1, 2)
         if len(obj) != len(img):

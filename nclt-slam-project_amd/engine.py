@@ -478,6 +478,18 @@ class Engine:
         self.sync()
         return int(nf[0])
 
+    def orb_features(self):
+        """descriptors and coordinates of the frame last extracted on the device (orb_frame_dev / a tick), copied to the host"""
+        nf = np.empty(1, np.int32)
+        self.d2h(nf, int(self._lib.reloc_frame_count_dev(self._ctx)))
+        n = min(int(nf[0]), self.max_feat)
+        desc = np.empty((n, 32), np.uint8)
+        xy = np.empty((n, 2), np.float32)
+        if n:
+            self.d2h(desc, int(self._lib.reloc_frame_desc_dev(self._ctx)))
+            self.d2h(xy, int(self._lib.reloc_frame_xy_dev(self._ctx)))
+        return dict(n=n, desc=desc, xy=xy)
+
     def tick_scan_into(self, img_dev: int, w: int, h: int, base_pose, k: int, ids_dev: int, counts_dev: int, nfeat_dev: int,
                        order_rgb=False):
         """ORB + shard scan + local top-k, everything left in caller-owned device memory (k ids, k counts, 1 feature count);

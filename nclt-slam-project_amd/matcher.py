@@ -42,6 +42,8 @@ class MatcherConfig:
     min_inliers: int = 10
     consistency_m: float = 5.0
     nfeatures: int = 500
+    gray_coeff_bits: int = 14      # cvtColor fixed point: 14 = SURVEY.md A.1, 15 = OpenCV 4.x (include/reloc_spec.h); fused path only --
+                                   # the cv2-shaped path takes it from its backend (Engine.set_params)
     # global relocalisation (variant G)
     global_reloc: bool = False
     reloc_age_s: float = 20.0
@@ -335,7 +337,8 @@ class FusedLandmarkMatcher:
                      accum_min_kpts=cfg.accum_min_kpts, candidate_radius_m=cfg.candidate_radius_m,
                      heading_tol_deg=cfg.heading_tol_deg, reproj_max_px=cfg.reproj_max_px,
                      ransac_reproj_px=cfg.ransac_reproj_px, consistency_m=cfg.consistency_m,
-                     global_reproj_max_px=cfg.reloc_reproj_max_px, accum_min_dist_m=cfg.accum_min_dist_m)
+                     global_reproj_max_px=cfg.reloc_reproj_max_px, accum_min_dist_m=cfg.accum_min_dist_m,
+                     gray_coeff_bits=cfg.gray_coeff_bits)
         e.set_camera([cfg.fx, cfg.fy, cfg.cx, cfg.cy], data.get("base_to_cam_translation", P.BASE_TO_CAM_TRANSLATION),
                      data.get("base_to_cam_rot", P.BASE_TO_CAM_ROT))
         self._return_src = return_landmarks

@@ -84,11 +84,11 @@ def _u8(a):
 
 
 # ---------------------------------------------------------------- ORB front end
-def gray_u8(img, order_rgb=False):
+def gray_u8(img, order_rgb=False, coeff_bits=14):
     img = _u8(img)
     h, w, _ = img.shape
     out = np.empty((h, w), np.uint8)
-    rc = lib().orc_gray_u8(_p(img), w, h, w * 3, int(order_rgb), _p(out), w)
+    rc = lib().orc_gray_u8_bits(_p(img), w, h, w * 3, int(order_rgb), _p(out), w, int(coeff_bits))
     assert rc == 0
     return out
 

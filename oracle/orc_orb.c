@@ -35,21 +35,31 @@
 #define ORC_API __attribute__((visibility("default")))
 
 /* ---- a2: cv2.cvtColor(.., COLOR_BGR2GRAY) (visual_landmark_matcher.py:305) ------------- */
-ORC_API int orc_gray_u8(const uint8_t *img, int w, int h, int stride, int order_rgb,
-                        uint8_t *gray, int gstride)
+/* coeff_bits: 14 = SURVEY.md A.1 (the default of reloc_params.gray_coeff_bits), 15 = OpenCV 4.x's gray_shift set */
+ORC_API int orc_gray_u8_bits(const uint8_t *img, int w, int h, int stride, int order_rgb,
+                             uint8_t *gray, int gstride, int coeff_bits)
 {
     if (!img || !gray || w <= 0 || h <= 0) return -1;
+    if (coeff_bits != RELOC_GRAY_SHIFT && coeff_bits != RELOC_GRAY15_SHIFT) return -2;
+    const int c15 = coeff_bits == RELOC_GRAY15_SHIFT;
+    const int cb = c15 ? RELOC_GRAY15_CB : RELOC_GRAY_CB, cg = c15 ? RELOC_GRAY15_CG : RELOC_GRAY_CG,
+              cr = c15 ? RELOC_GRAY15_CR : RELOC_GRAY_CR;
     for (int y = 0; y < h; ++y) {
         const uint8_t *s = img + (size_t)y * stride;
         uint8_t *d = gray + (size_t)y * gstride;
         for (int x = 0; x < w; ++x) {
             int c0 = s[3 * x], c1 = s[3 * x + 1], c2 = s[3 * x + 2];
             int b = order_rgb ? c2 : c0, r = order_rgb ? c0 : c2;
-            d[x] = (uint8_t)((b * RELOC_GRAY_CB + c1 * RELOC_GRAY_CG + r * RELOC_GRAY_CR +
-                              (1 << (RELOC_GRAY_SHIFT - 1))) >> RELOC_GRAY_SHIFT);
+            d[x] = (uint8_t)((b * cb + c1 * cg + r * cr + (1 << (coeff_bits - 1))) >> coeff_bits);
         }
     }
     return 0;
+}
+
+ORC_API int orc_gray_u8(const uint8_t *img, int w, int h, int stride, int order_rgb,
+                        uint8_t *gray, int gstride)
+{
+    return orc_gray_u8_bits(img, w, h, stride, order_rgb, gray, gstride, RELOC_GRAY_SHIFT);
 }
 
 /* ---- a4: pyramid geometry and per-level feature quotas ---------------- */

@@ -10,9 +10,10 @@ from oracle import oracle as O
 
 class OracleBackend:
     max_feat = 8192
+    gray_coeff_bits = 14           # the oracle-side twin of reloc_params.gray_coeff_bits
 
     def gray(self, img, order_rgb=False):
-        return O.gray_u8(img, order_rgb)
+        return O.gray_u8(img, order_rgb, self.gray_coeff_bits)
 
     def orb_detect_compute(self, gray, nfeatures=500):
         r = O.orb_detect_compute(gray, nfeatures, max_out=self.max_feat)

@@ -25,6 +25,37 @@ def test_gray(engine, oracle, order_rgb):
     assert list(g[0, ::16]) == [(255 * 1868 + 8192) >> 14, (255 * 9617 + 8192) >> 14, (255 * 4899 + 8192) >> 14, 255]
 
 
+@pytest.mark.parametrize("bits", [14, 15])
+def test_gray_coefficient_sets(engine, oracle, bits):
+    """reloc_params.gray_coeff_bits: both conventions, through the plain gray kernel and through the fused pyramid (the
+    tick's input path), both channel orders, against the oracle's twin switch"""
+    img = _frame(31, 640, 480)
+    with pytest.raises(Exception):
+        engine.set_params(gray_coeff_bits=13)
+    engine.set_params(gray_coeff_bits=bits)
+    try:
+        assert engine.get_params().gray_coeff_bits == bits
+        for order_rgb in (False, True):
+            exp = oracle.gray_u8(img, order_rgb, coeff_bits=bits)
+            np.testing.assert_array_equal(engine.gray(img, order_rgb), exp)
+            dev = engine.dev_alloc(img.nbytes)
+            try:
+                engine.h2d(dev, img)
+                n = engine.orb_frame_dev(dev, 640, 480, 3 * 640, order_rgb=order_rgb)
+            finally:
+                engine.dev_free(dev)
+            np.testing.assert_array_equal(engine.frame_debug_plane(0, 0), exp)
+            ref = oracle.orb_detect_compute(exp, 500, max_out=engine.max_feat)
+            assert n == ref["n"]
+            got = engine.orb_features()
+            np.testing.assert_array_equal(got["desc"], ref["desc"])
+            np.testing.assert_array_equal(got["xy"].view(np.uint32), ref["xy"].view(np.uint32))
+    finally:
+        engine.set_params(gray_coeff_bits=14)
+    if bits == 15:
+        assert (oracle.gray_u8(img, coeff_bits=15) != oracle.gray_u8(img, coeff_bits=14)).any()
+
+
 @pytest.mark.parametrize("seed,w,h", [(2, 640, 480), (3, 1280, 720), (4, 333, 251), (5, 64, 64), (6, 100, 500)])
 def test_orb_stages_and_features(engine, oracle, seed, w, h):
     img = _frame(seed, w, h, n_shapes=max(40, w * h // 800))

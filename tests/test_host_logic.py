@@ -342,6 +342,19 @@ def test_cv2_shim_surface(oracle):
     np.testing.assert_allclose(cv2.Rodrigues(R)[0].ravel(), r.ravel(), atol=1e-9)
     ok, _, _, inl = cv2.solvePnPRansac(obj[:3], imgp[:3], K, None)
     assert not ok and inl is None
+    # the reference's history switches ITERATIVE <-> EPNP (M:342-348): every accepted flag is the same solver, same result
+    for fl in (cv2.SOLVEPNP_EPNP, cv2.SOLVEPNP_P3P, cv2.SOLVEPNP_AP3P):
+        ok2, r2, t2, inl2 = cv2.solvePnPRansac(obj, imgp, K, None, iterationsCount=200, reprojectionError=3.0, flags=fl)
+        assert ok2 and np.array_equal(r2, r) and np.array_equal(t2, t) and np.array_equal(inl2, inliers)
+    # nothing is accepted and silently ignored
+    with pytest.raises(cv2.error):
+        cv2.solvePnPRansac(obj, imgp, K, None, flags=3)                   # SOLVEPNP_DLS
+    with pytest.raises(cv2.error):
+        cv2.solvePnPRansac(obj, imgp, K, None, flags=8)                   # SOLVEPNP_SQPNP
+    with pytest.raises(cv2.error):
+        cv2.solvePnPRansac(obj, imgp, K, None, rvec=r, tvec=t, useExtrinsicGuess=True)
+    with pytest.raises(cv2.error):
+        cv2.solvePnPRansac(obj, imgp, K, np.array([0.1, 0, 0, 0]))
 
 
 def test_selftest_harness_passes_on_own_teach_frames(oracle):

@@ -22,6 +22,22 @@ def test_gray_formula(oracle):
     np.testing.assert_array_equal(oracle.gray_u8(img[..., ::-1].copy(), order_rgb=True), exp)
 
 
+def test_gray_formula_15_bit_set(oracle):
+    """reloc_params.gray_coeff_bits = 15: OpenCV 4.x's published 8-bit coefficients; within 1 grey level of the 14-bit set"""
+    rng = np.random.default_rng(10)
+    img = rng.integers(0, 256, (41, 67, 3), dtype=np.uint8)
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    exp = ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+    got = oracle.gray_u8(img, coeff_bits=15)
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(oracle.gray_u8(img[..., ::-1].copy(), order_rgb=True, coeff_bits=15), exp)
+    d = got.astype(int) - oracle.gray_u8(img).astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).any()                        # the two conventions really differ, by one level
+    assert 3735 + 19235 + 9798 == 1 << 15 and 1868 + 9617 + 4899 == 1 << 14   # both sets are normalised: white stays 255
+    full = np.full((2, 2, 3), 255, np.uint8)
+    assert (oracle.gray_u8(full, coeff_bits=15) == 255).all() and (oracle.gray_u8(full) == 255).all()
+
+
 def test_layout_matches_survey(oracle):
     lw, lh, sc, q = oracle.orb_layout(640, 480, 500)
     assert list(lw) == [640, 533, 444, 370, 309, 257, 214, 179]
