@@ -81,6 +81,7 @@ SIGNATURES = {
     "reloc_shard_merge_dev": (C.c_int, [c_ctx, P, C.c_int, i64, C.c_int, C.c_int, i64, i64, P, P, P]),
     "reloc_shard_solve_batch_dev": (C.c_int, [P, C.c_int, P, C.c_int, P, P, P]),
     "reloc_tick_result": (C.c_int, [c_ctx, P, P, P, P, P, P]),
+    "reloc_tick_wait": (C.c_int, [c_ctx]),
     "reloc_tick_scan_dev": (C.c_int, [c_ctx, P, C.c_int, C.c_int, C.c_int, P, P, P, C.c_int]),
     "reloc_tick_solve_dev": (C.c_int, [c_ctx, P, C.c_int, P, C.c_int, u64]),
 }

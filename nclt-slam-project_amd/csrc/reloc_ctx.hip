@@ -181,7 +181,7 @@ RELOC_API void reloc_destroy(reloc_ctx *c)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < RELOC_PROF_N; ++k)
         if (c->prof[k].init)
-            for (int i = 0; i < 64; ++i) {
+            for (int i = 0; i < RELOC_PROF_RING; ++i) {
                 (void)hipEventDestroy(c->prof[k].a[i]);
                 (void)hipEventDestroy(c->prof[k].b[i]);
             }
@@ -348,10 +348,10 @@ void reloc_prof_begin(reloc_ctx *c, int which)
     if (!c->prof_on) return;
     auto &p = c->prof[which];
     if (!p.init) {
-        for (int i = 0; i < 64; ++i) { (void)hipEventCreate(&p.a[i]); (void)hipEventCreate(&p.b[i]); }
+        for (int i = 0; i < RELOC_PROF_RING; ++i) { (void)hipEventCreate(&p.a[i]); (void)hipEventCreate(&p.b[i]); }
         p.init = true;
     }
-    if (p.n == 64) prof_flush(c, which);
+    if (p.n == RELOC_PROF_RING) prof_flush(c, which);
     (void)hipEventRecord(p.a[p.n], c->stream);
 }
 

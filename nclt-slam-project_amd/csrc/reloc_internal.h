@@ -9,6 +9,7 @@
 #include "../../include/reloc_spec.h"
 
 #define RELOC_API extern "C" __attribute__((visibility("default")))
+#define RELOC_PROF_RING 256      /* event pairs per stopwatch before reloc_prof_begin has to wait for the device */
 
 void reloc_set_error(const char *fmt, ...);
 
@@ -76,7 +77,7 @@ struct TickResult {
     int32_t n_candidates;
     int32_t n_features;
     int32_t relocating;   // candidates came from the whole-database search (G:344)
-    int32_t pad[2];       // 96 bytes
+    int32_t pad[2];       // 96 bytes; pad[0] of a record in HOST memory: the tick's sequence stamp, stored last (reloc_tick_wait)
 };
 static_assert(sizeof(TickResult) == 96, "TickResult is the 96-byte record documented in include/reloc.h");
 
@@ -221,7 +222,9 @@ struct reloc_ctx {
 
     // profiling
     int prof_on = 0;
-    struct ProfSlot { hipEvent_t a[64], b[64]; int n = 0; float total = 0.f; int launches = 0; bool init = false; } prof[RELOC_PROF_N];
+    // ring of event pairs per stopwatch: large enough that a measurement of a few hundred launches never has to wait for
+    // the device in the middle (prof_flush synchronises)
+    struct ProfSlot { hipEvent_t a[RELOC_PROF_RING], b[RELOC_PROF_RING]; int n = 0; float total = 0.f; int launches = 0; bool init = false; } prof[RELOC_PROF_N];
 
     // generic scratch (grown on demand by host-pointer entry points)
     void *scratch[8] = {};
@@ -305,6 +308,7 @@ struct reloc_ctx {
     bool local_two_stage = false;    // developer switch RELOC_LOCAL_TWO_STAGE=1: local candidates by k_topk_part + k_candidates_local
     TickResult *tick_res = nullptr;  // 1
     TickResult *tick_res_host = nullptr;   // the same record in pinned host memory, written by k_tick_finalize
+    int32_t tick_seq = 0;                  // stamp of the last tick enqueued (TickResult.pad[0] of its host records); 0: none yet
     TickResult *tick_res_ext = nullptr;    // caller's pinned record for the next ticks (reloc_tick_result_to), or NULL
 };
 

@@ -193,6 +193,10 @@ template <int NJ, int R, bool FLEX>
 __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, int nr, const u32 (&q)[NJ][8],
                                            u32 colbase, u32 *rowkey, u32 *colbest, bool single_cb, int lane)
 {
+    // (Measured and dropped in round 3: the running best row of every column kept in a per-wave slice of LDS and updated with
+    // ds_min_u32, one LDS instruction per column and row, instead of v_min_u16 in registers -- one VALU instruction less
+    // per pair, 19.1 instead of 20.1, bit-identical: 154.4 / 156.2 vs 150.4 / 153.5 us at 10 000 records, 1305 vs 1302 us at
+    // 100 000, profiles/r3_scan_lds_colmin.log.  The LDS instruction costs the wave an issue turn all the same.)
     u32 cb16[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
@@ -811,9 +815,64 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
 constexpr int SQ_MAX_ROWS = 1024;
 constexpr int SQ_WAVES = 4;
 
-// G = queries per butterfly group (4, 8 or 16): a call with 1-4 queries evaluates 4 distances per row, not 16
-template <int G>
-__global__ __launch_bounds__(64 * SQ_WAVES) void k_db_scan_rows(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
+// The same register-tile butterfly as rows_min<R> on keys that fit 16 bits (v_min_u16: full rate; v_min_u32: half rate).
+__device__ __forceinline__ u32 shl6_u16(u32 a)
+{
+    u32 r;
+    asm("v_lshlrev_b16 %0, 6, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ u32 bfly16(u32 a, u32 b, int lane)
+{
+    if constexpr (K == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        return min_u16(r[0], r[1]);
+    } else if constexpr (K == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        return min_u16(r[0], r[1]);
+    } else {
+        const bool hi = lane & K;
+        const u32 mine = hi ? b : a;
+        const u32 theirs = hi ? a : b;
+        return min_u16(mine, dpp_xor<K>(theirs));
+    }
+}
+template <int R>
+__device__ __forceinline__ u32 rows_min16(u32 (&d)[R], int lane)
+{
+    if constexpr (R >= 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = bfly16<8>(d[i], d[i + 8], lane);
+    }
+    if constexpr (R >= 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = bfly16<4>(d[i], d[i + 4], lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) d[i] = bfly16<2>(d[i], d[i + 2], lane);
+    u32 x = bfly16<1>(d[0], d[1], lane);
+    if constexpr (R <= 4) x = min_u16(x, dpp_xor<4>(x));
+    if constexpr (R <= 8) x = min_u16(x, dpp_xor<8>(x));
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        x = min_u16(r[0], r[1]);
+        const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        x = min_u16(q[0], q[1]);
+    }
+    return x;
+}
+
+// G = queries per butterfly group (4, 8 or 16): a call with 1-4 queries evaluates 4 distances per row, not 16.
+// HOIST (capacity <= G = 4 queries: ONE group): the query words are fetched once per wave and stay in SGPRs (eight queries
+// = 64 SGPRs do not fit beside the loop state: the compiler spills them to VGPR lanes, measured 57 vs 48 us at Q = 8).  Otherwise
+// the queries arrive four at a time, requested together -- round 2 fetched each query through the scalar cache inside the row
+// loop and waited for it, eight dependent round trips per record.
+// Both keys are 16-bit (distance << 6 | query resp. lane, < 2^15): v_lshlrev_b16 / v_or / v_min_u16, all full rate.
+// A wave takes two records per turn and requests the first 64 rows of both before it works on either, so half of its HBM
+// latency runs under its own arithmetic instead of only under that of the SIMD's other waves.
+template <int G, bool HOIST>
+__global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_db_scan_rows(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
                                                                 const uint4 *__restrict__ cur, const int32_t *__restrict__ n_cur_p,
                                                                 int n_cur_max, int32_t *__restrict__ counts)
 {
@@ -825,31 +884,67 @@ __global__ __launch_bounds__(64 * SQ_WAVES) void k_db_scan_rows(const uint4 *__r
     u32 *col = s_col[wave];
     unsigned short *rowk = s_row[wave];
     const int gw = blockIdx.x * SQ_WAVES + wave, nw = gridDim.x * SQ_WAVES;
-    for (int r = gw; r < n_rec; r += nw) {
-        const int64_t row0 = off[r];
-        const int n = (int)(off[r + 1] - row0);
-        if (n <= 0 || C <= 0) { if (lane == 0) counts[r] = 0; continue; }
+    u32 qs[HOIST ? G : 1][8];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int q = max(min(j, C - 1), 0);        // wave-uniform; repeats of the last query lose every tie (larger index)
+            const uint4 qa = cur[2 * q], qb = cur[2 * q + 1];                // scalar loads, once
+            qs[j][0] = qa.x; qs[j][1] = qa.y; qs[j][2] = qa.z; qs[j][3] = qa.w;
+            qs[j][4] = qb.x; qs[j][5] = qb.y; qs[j][6] = qb.z; qs[j][7] = qb.w;
+        }
+    }
+    // first chunk (rows 0..63, lanes past the end repeat the last row) of record r; a record without rows fetches nothing
+    auto fetch0 = [&](int r, int64_t &row0, int &n, uint4 &a, uint4 &b) {
+        row0 = off[r];
+        n = (int)(off[r + 1] - row0);
+        if (n > 0) {
+            const int row = min(lane, n - 1);
+            a = db[2 * (row0 + row)]; b = db[2 * (row0 + row) + 1];
+        }
+    };
+    // one record; (a, b) = its first 64 rows, already requested
+    auto process = [&](int r, int64_t row0, int n, uint4 a, uint4 b) {
+        if (n <= 0 || C <= 0) {
+            if (lane == 0) counts[r] = 0;
+            return;
+        }
         col[lane] = 0xFFFFFFFFu;
         for (int tc = 0; tc < n; tc += 64) {
-            const int row = min(tc + lane, n - 1);      // lanes past the end repeat the last row: a duplicate with a larger index never wins
-            const uint4 a = db[2 * (row0 + row)], b = db[2 * (row0 + row) + 1];
+            if (tc > 0) {                                                  // records of more than 64 rows: further chunks on demand
+                const int row = min(tc + lane, n - 1);
+                a = db[2 * (row0 + row)]; b = db[2 * (row0 + row) + 1];
+            }
             const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            u32 rbest = 0xFFFFFFFFu;
-            for (int q0 = 0; q0 < C; q0 += G) {
+            u32 rbest = 0xFFFFu;
+            for (int q0 = 0; q0 < (HOIST ? 1 : C); q0 += G) {
                 u32 ck[G];
-                // (G pinned accumulator chains as in ham8_cols, query words as SGPR operands: measured slower here, 19.9 vs 17.8 us
-                // at Q = 32 -- this kernel waits on its row loads, not on the v_bcnt chain)
 #pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const int q = min(q0 + j, C - 1);   // wave-uniform; repeats of the last query lose every tie (larger index)
-                    const uint4 qa = cur[2 * q], qb = cur[2 * q + 1];        // scalar loads
-                    u32 h = 0;
-                    h = bcnt_acc(w[0] ^ qa.x, h); h = bcnt_acc(w[1] ^ qa.y, h); h = bcnt_acc(w[2] ^ qa.z, h); h = bcnt_acc(w[3] ^ qa.w, h);
-                    h = bcnt_acc(w[4] ^ qb.x, h); h = bcnt_acc(w[5] ^ qb.y, h); h = bcnt_acc(w[6] ^ qb.z, h); h = bcnt_acc(w[7] ^ qb.w, h);
-                    rbest = umin(rbest, (h << 6) | (u32)(q0 + j));
-                    ck[j] = (h << 6) | (u32)lane;
+                for (int j4 = 0; j4 < G; j4 += 4) {
+                    // four queries at a time: their 32 words are requested together (32 SGPRs; eight at once would not fit the
+                    // scalar register file beside the loop's own state)
+                    u32 qw[4][8];
+                    if constexpr (!HOIST) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int q = min(q0 + j4 + jj, C - 1);      // wave-uniform; repeats of the last query lose every tie (larger index)
+                            const uint4 qa = cur[2 * q], qb = cur[2 * q + 1];
+                            qw[jj][0] = qa.x; qw[jj][1] = qa.y; qw[jj][2] = qa.z; qw[jj][3] = qa.w;
+                            qw[jj][4] = qb.x; qw[jj][5] = qb.y; qw[jj][6] = qb.z; qw[jj][7] = qb.w;
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = j4 + jj;
+                        u32 h = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) h = bcnt_acc(w[k] ^ (HOIST ? qs[j][k] : qw[jj][k]), h);
+                        const u32 hs = shl6_u16(h);                        // distance <= 256: (256 << 6 | 63) < 2^15
+                        rbest = min_u16(rbest, hs | (u32)(q0 + j));
+                        ck[j] = hs | (u32)lane;
+                    }
                 }
-                const u32 m = rows_min<G>(ck, lane);    // lane l: best (distance, lane) of query q0 + (l & (G - 1)) over the 64 rows
+                const u32 m = rows_min16<G>(ck, lane);  // lane l: best (distance, lane) of query q0 + (l & (G - 1)) over the 64 rows
                 if (lane < G && q0 + lane < C) {
                     const u32 key = ((m >> 6) << 16) | (u32)(tc + (int)(m & 63u));
                     if (key < col[q0 + lane]) col[q0 + lane] = key;          // one wave: plain read-modify-write
@@ -868,6 +963,19 @@ __global__ __launch_bounds__(64 * SQ_WAVES) void k_db_scan_rows(const uint4 *__r
             total += __popcll(__ballot(mutual));
         }
         if (lane == 0) counts[r] = total;
+    };
+    // Two records per turn: both first chunks are requested before either is worked on, so the second record's HBM latency
+    // runs under the first record's arithmetic.  (A prefetch carried around the loop does not survive the compiler: the
+    // register copy at the back edge is a use, and its s_waitcnt vmcnt(0) sits in front of the next request -- ISA checked.)
+    for (int r = gw; r < n_rec; r += 2 * nw) {
+        int64_t row0_a = 0, row0_b = 0;
+        int n_a = 0, n_b = 0;
+        uint4 a0 = {}, b0 = {}, a1 = {}, b1 = {};
+        const bool two = r + nw < n_rec;
+        fetch0(r, row0_a, n_a, a0, b0);
+        if (two) fetch0(r + nw, row0_b, n_b, a1, b1);
+        process(r, row0_a, n_a, a0, b0);
+        if (two) process(r + nw, row0_b, n_b, a1, b1);
     }
 }
 
@@ -889,10 +997,10 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         int grid = ctx->num_cu * 8;                        // 8 workgroups of 4 waves per CU
         const int need = (n_ids_max + SQ_WAVES - 1) / SQ_WAVES;
         if (grid > need) grid = need;
-#define RELOC_LAUNCH_ROWS(G)                                                                                                  \
-    hipLaunchKernelGGL(k_db_scan_rows<G>, dim3(grid), dim3(64 * SQ_WAVES), 0, ctx->stream, (const uint4 *)db_desc, db_off, n_ids_max, \
+#define RELOC_LAUNCH_ROWS(G, HOIST)                                                                                           \
+    hipLaunchKernelGGL((k_db_scan_rows<G, HOIST>), dim3(grid), dim3(64 * SQ_WAVES), 0, ctx->stream, (const uint4 *)db_desc, db_off, n_ids_max, \
                        (const uint4 *)cur, n_cur_dev, n_cur_max, counts)
-        if (n_cur_max <= 4) RELOC_LAUNCH_ROWS(4); else if (n_cur_max <= 8) RELOC_LAUNCH_ROWS(8); else RELOC_LAUNCH_ROWS(16);
+        if (n_cur_max <= 4) RELOC_LAUNCH_ROWS(4, true); else if (n_cur_max <= 8) RELOC_LAUNCH_ROWS(8, false); else RELOC_LAUNCH_ROWS(16, false);
 #undef RELOC_LAUNCH_ROWS
         HIP_TRY(hipGetLastError());
         return RELOC_OK;

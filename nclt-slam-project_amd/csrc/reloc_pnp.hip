@@ -7,8 +7,8 @@
 // and the mean inlier reprojection error of M:353-356.
 //
 // Three kernels per batch:
-//   k_pnp_hyp     one lane per (candidate, hypothesis): counter-based sampler, P3P on three points,
-//                 fourth point picks the root.  IEEE double add/sub/mul/div/sqrt only, no FMA, so the
+//   k_pnp_hyp     four lanes per (candidate, hypothesis): counter-based sampler, P3P on three points, one lane per
+//                 root of the quartic, the fourth point picks the root.  IEEE double add/sub/mul/div/sqrt only, no FMA, so the
 //                 pose list is bit-identical to the specification.
 //   k_pnp_score   one wave per (candidate, hypothesis): reprojection error of every correspondence,
 //                 inlier count by ballot.  This is the data-parallel bulk (H x m projections).
@@ -16,6 +16,21 @@
 //                 inlier list by ballot compaction, LM refinement with the 6x6 normal equations
 //                 summed across the wave in fp64, Rodrigues log, mean inlier error.
 #include "reloc_internal.h"
+
+// Developer build (-DRELOC_PNP_TIMING, tools/exp_pnp_phases.py): the first wave of each PnP kernel stamps the 100 MHz
+// wall clock at its phase boundaries.  Not compiled into the product library.
+#ifdef RELOC_PNP_TIMING
+__device__ unsigned long long g_pnp_phase[32];
+#define PNP_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_pnp_phase[i] = wall_clock64(); } while (0)
+#define PNP_V(i, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_pnp_phase[i] = (unsigned long long)(v); } while (0)
+RELOC_API int reloc_debug_pnp_phases(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_phase), sizeof(g_pnp_phase)) == hipSuccess ? 0 : -1;
+}
+#else
+#define PNP_T(i) do { } while (0)
+#define PNP_V(i, v) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // deterministic helpers (mirror the arithmetic order of the specification exactly)
@@ -56,40 +71,65 @@ __device__ double log_spec(double x)
     return (double)e * 0.69314718055994530942 + p;
 }
 
-__device__ int ransac_update_iters(double conf, double outlier_ratio, int max_iters)
+// the adaptive iteration cap; log_num = ransac_log_num(conf) does not change inside a RANSAC run and is taken once
+__device__ double ransac_log_num(double conf)
 {
     const double DBL_MIN_ = 2.2250738585072014e-308;
     const double p = conf < 0 ? 0 : (conf > 1 ? 1 : conf);
-    const double ep = outlier_ratio < 0 ? 0 : (outlier_ratio > 1 ? 1 : outlier_ratio);
     double num = 1.0 - p; if (num < DBL_MIN_) num = DBL_MIN_;
+    return log_spec(num);
+}
+__device__ int ransac_update_iters(double log_num, double outlier_ratio, int max_iters)
+{
+    const double DBL_MIN_ = 2.2250738585072014e-308;
+    const double ep = outlier_ratio < 0 ? 0 : (outlier_ratio > 1 ? 1 : outlier_ratio);
     const double w = 1.0 - ep, w2 = w * w, w4 = w2 * w2;
     double den = 1.0 - w4;
     if (den < DBL_MIN_) return 0;
-    num = log_spec(num);
+    const double num = log_num;
     den = log_spec(den);
     if (den >= 0 || -num >= (double)max_iters * (-den)) return max_iters;
     return (int)rint(num / den);
 }
 
+// safeguarded Halley iteration from a Fujiwara-type bound, RELOC_P3P_CUBIC_ITERS steps at most (include/reloc_spec.h)
 __device__ double cubic_pos_root(double c2, double c1, double c0)
 {
     double lo = 0.0, hi = 1.0 + fabs(c2);
     if (fabs(c1) + 1.0 > hi) hi = fabs(c1) + 1.0;
     if (fabs(c0) + 1.0 > hi) hi = fabs(c0) + 1.0;
-    double x = hi;
-    for (int it = 0; it < 80; ++it) {
+    /* start: every real root of t^3 + P t + Q (t = x + c2 / 3) lies below 2 max(|P|^(1/2), |Q / 2|^(1/3)) (Fujiwara);
+     * the cube root is replaced by the next power of two above it (exponent arithmetic only: exact everywhere) */
+    const double P = c1 - c2 * c2 / 3.0;
+    const double Q = (2.0 * c2 * c2 * c2 - 9.0 * c2 * c1) / 27.0 + c0;
+    double b = sqrt(fabs(P));
+    if (Q != 0.0) {
+        int e;
+        (void)frexp(fabs(Q) * 0.5, &e);                      /* |Q| / 2 = m 2^e, 0.5 <= m < 1 */
+        const int k = e >= 0 ? (e + 2) / 3 : -((-e) / 3);     /* ceil(e / 3) */
+        const double cb = ldexp(1.0, k);
+        if (cb > b) b = cb;
+    }
+    double x = 2.0 * b - c2 / 3.0;
+    if (!(x > lo)) x = lo;
+    if (!(x < hi)) x = hi;
+    for (int it = 0; it < RELOC_P3P_CUBIC_ITERS; ++it) {
         const double g = ((x + c2) * x + c1) * x + c0;
         const double dg = (3.0 * x + 2.0 * c2) * x + c1;
+        const double ddg = 6.0 * x + 2.0 * c2;
         if (g > 0) hi = x; else lo = x;
-        double xn = x - g / dg;
-        if (!(dg != 0.0) || !(xn > lo) || !(xn < hi)) xn = 0.5 * (lo + hi);
+        const double den = 2.0 * dg * dg - g * ddg;
+        double xn = x - 2.0 * g * dg / den;                   /* Halley */
+        if (!(den != 0.0) || !(xn > lo) || !(xn < hi)) xn = 0.5 * (lo + hi);
         if (xn == x) break;
         x = xn;
     }
     return x;
 }
 
-__device__ int quartic_real_roots(const double A[5], double roots[4])
+// Ferrari: the (up to 4) real roots of A4 v^4 + ... + A0 before their Newton polish, in the order the specification
+// lists them; returns the count.  shift = a / 4 (root of the quartic = y - shift).
+__device__ int quartic_root_starts(const double A[5], double y[4], double &shift)
 {
     double amax = 0;
     for (int i = 0; i < 5; ++i) if (fabs(A[i]) > amax) amax = fabs(A[i]);
@@ -99,7 +139,7 @@ __device__ int quartic_real_roots(const double A[5], double roots[4])
     const double p = b - 0.375 * a2;
     const double q = c - 0.5 * a * b + 0.125 * a2 * a;
     const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
-    double y[4];
+    shift = 0.25 * a;
     int n = 0;
     const double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
     if (fabs(q) <= 1e-14 * scale * sqrt(scale)) {
@@ -112,6 +152,7 @@ __device__ int quartic_real_roots(const double A[5], double roots[4])
         }
     } else {
         const double m = cubic_pos_root(p, 0.25 * p * p - r, -0.125 * q * q);
+        PNP_T(4);
         if (!(m > 0)) return 0;
         const double s = sqrt(2.0 * m);
         const double t = q / (2.0 * s);
@@ -121,16 +162,17 @@ __device__ int quartic_real_roots(const double A[5], double roots[4])
         if (d1 >= 0) { const double sd = sqrt(d1); y[n++] = 0.5 * (-s + sd); y[n++] = 0.5 * (-s - sd); }
         if (d2 >= 0) { const double sd = sqrt(d2); y[n++] = 0.5 * (s + sd); y[n++] = 0.5 * (s - sd); }
     }
-    for (int i = 0; i < n; ++i) {
-        double v = y[i] - 0.25 * a;
-        for (int it = 0; it < 3; ++it) {
-            const double f = (((A[4] * v + A[3]) * v + A[2]) * v + A[1]) * v + A[0];
-            const double df = ((4.0 * A[4] * v + 3.0 * A[3]) * v + 2.0 * A[2]) * v + A[1];
-            if (df != 0.0) { const double vn = v - f / df; if (vn == vn) v = vn; }
-        }
-        roots[i] = v;
-    }
     return n;
+}
+// three Newton steps on the quartic itself
+__device__ __forceinline__ double quartic_polish(const double A[5], double v)
+{
+    for (int it = 0; it < 3; ++it) {
+        const double f = (((A[4] * v + A[3]) * v + A[2]) * v + A[1]) * v + A[0];
+        const double df = ((4.0 * A[4] * v + 3.0 * A[3]) * v + 2.0 * A[2]) * v + A[1];
+        if (df != 0.0) { const double vn = v - f / df; if (vn == vn) v = vn; }
+    }
+    return v;
 }
 
 __device__ __forceinline__ double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -160,12 +202,20 @@ __device__ bool frame3(const double *p0, const double *p1, const double *p2, dou
     return true;
 }
 
-__device__ int p3p(const double P[9], const double xn[6], double Rt[48])
+// P3P in two halves, so that the <= 4 roots of a hypothesis can be worked on by 4 lanes:
+//   p3p_setup    bearing vectors, quartic coefficients, the unpolished roots, the object frame        (per hypothesis)
+//   p3p_solution polish of root i, depths, camera frame, R | t                                         (per root)
+// The arithmetic of each half is the specification's, operation by operation.
+struct P3pSetup {
+    double f[3][3], N[3], D[2], A[5], cb, b2, Fp[9], y[4], shift;
+    int nr;
+};
+__device__ bool p3p_setup(const double P[9], const double xn[6], P3pSetup &S)
 {
-    double f[3][3];
+    S.nr = 0;
     for (int i = 0; i < 3; ++i) {
-        f[i][0] = xn[2 * i]; f[i][1] = xn[2 * i + 1]; f[i][2] = 1.0;
-        if (!unit3(f[i])) return 0;
+        S.f[i][0] = xn[2 * i]; S.f[i][1] = xn[2 * i + 1]; S.f[i][2] = 1.0;
+        if (!unit3(S.f[i])) return false;
     }
     double d12[3], d02[3], d01[3];
     for (int k = 0; k < 3; ++k) {
@@ -174,8 +224,8 @@ __device__ int p3p(const double P[9], const double xn[6], double Rt[48])
         d01[k] = P[k] - P[3 + k];
     }
     const double a2 = dot3(d12, d12), b2 = dot3(d02, d02), c2 = dot3(d01, d01);
-    if (!(a2 > 0) || !(b2 > 0) || !(c2 > 0)) return 0;
-    const double ca = dot3(f[1], f[2]), cb = dot3(f[0], f[2]), cg = dot3(f[0], f[1]);
+    if (!(a2 > 0) || !(b2 > 0) || !(c2 > 0)) return false;
+    const double ca = dot3(S.f[1], S.f[2]), cb = dot3(S.f[0], S.f[2]), cg = dot3(S.f[0], S.f[1]);
     const double K = (a2 - c2) / b2, q = c2 / b2;
     const double N[3] = {1.0 + K, -2.0 * K * cb, K - 1.0};
     const double D[2] = {2.0 * cg, -2.0 * ca};
@@ -185,38 +235,41 @@ __device__ int p3p(const double P[9], const double xn[6], double Rt[48])
     const double W[3] = {1.0 - q, 2.0 * q * cb, -q};
     const double DW[5] = {DD[0] * W[0], DD[0] * W[1] + DD[1] * W[0], DD[0] * W[2] + DD[1] * W[1] + DD[2] * W[0],
                           DD[1] * W[2] + DD[2] * W[1], DD[2] * W[2]};
-    double A[5];
-    for (int i = 0; i < 5; ++i) A[i] = NN[i] + DW[i];
-    for (int i = 0; i < 4; ++i) A[i] -= 2.0 * cg * ND[i];
-    double roots[4];
-    const int nr = quartic_real_roots(A, roots);
-    double Fp[9];
-    if (!frame3(P, P + 3, P + 6, Fp)) return 0;
-    int ns = 0;
-    for (int i = 0; i < nr; ++i) {
-        const double v = roots[i];
-        if (!(v > 0)) continue;
-        const double Dv = D[1] * v + D[0];
-        if (!(fabs(Dv) > 1e-12)) continue;
-        const double u = ((N[2] * v + N[1]) * v + N[0]) / Dv;
-        if (!(u > 0)) continue;
-        const double den = 1.0 + v * v - 2.0 * v * cb;
-        if (!(den > 1e-300)) continue;
-        const double s0 = sqrt(b2 / den), s1 = u * s0, s2 = v * s0;
-        double C[3][3];
-        for (int k = 0; k < 3; ++k) { C[0][k] = s0 * f[0][k]; C[1][k] = s1 * f[1][k]; C[2][k] = s2 * f[2][k]; }
-        double Fc[9];
-        if (!frame3(C[0], C[1], C[2], Fc)) continue;
-        double *R = Rt + 12 * ns, *t = R + 9;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-                R[3 * r + c] = Fc[3 * r] * Fp[3 * c] + Fc[3 * r + 1] * Fp[3 * c + 1] + Fc[3 * r + 2] * Fp[3 * c + 2];
-        for (int r = 0; r < 3; ++r) t[r] = C[0][r] - (R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2]);
-        bool ok = true;
-        for (int k = 0; k < 12; ++k) ok &= R[k] == R[k];
-        if (ok) ++ns;
-    }
-    return ns;
+    for (int i = 0; i < 5; ++i) S.A[i] = NN[i] + DW[i];
+    for (int i = 0; i < 4; ++i) S.A[i] -= 2.0 * cg * ND[i];
+    for (int i = 0; i < 3; ++i) S.N[i] = N[i];
+    S.D[0] = D[0]; S.D[1] = D[1]; S.cb = cb; S.b2 = b2;
+    PNP_T(3);
+    S.nr = quartic_root_starts(S.A, S.y, S.shift);
+    PNP_T(5);
+    if (!frame3(P, P + 3, P + 6, S.Fp)) { S.nr = 0; return false; }
+    return true;
+}
+// root i -> R | t (12 doubles); false: the root gives no pose
+__device__ bool p3p_solution(const P3pSetup &S, const double P[9], int i, double *Rt)
+{
+    if (i >= S.nr) return false;
+    const double v = quartic_polish(S.A, S.y[i] - S.shift);
+    if (!(v > 0)) return false;
+    const double Dv = S.D[1] * v + S.D[0];
+    if (!(fabs(Dv) > 1e-12)) return false;
+    const double u = ((S.N[2] * v + S.N[1]) * v + S.N[0]) / Dv;
+    if (!(u > 0)) return false;
+    const double den = 1.0 + v * v - 2.0 * v * S.cb;
+    if (!(den > 1e-300)) return false;
+    const double s0 = sqrt(S.b2 / den), s1 = u * s0, s2 = v * s0;
+    double C[3][3];
+    for (int k = 0; k < 3; ++k) { C[0][k] = s0 * S.f[0][k]; C[1][k] = s1 * S.f[1][k]; C[2][k] = s2 * S.f[2][k]; }
+    double Fc[9];
+    if (!frame3(C[0], C[1], C[2], Fc)) return false;
+    double *R = Rt, *t = R + 9;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            R[3 * r + c] = Fc[3 * r] * S.Fp[3 * c] + Fc[3 * r + 1] * S.Fp[3 * c + 1] + Fc[3 * r + 2] * S.Fp[3 * c + 2];
+    for (int r = 0; r < 3; ++r) t[r] = C[0][r] - (R[3 * r] * P[0] + R[3 * r + 1] * P[1] + R[3 * r + 2] * P[2]);
+    bool ok = true;
+    for (int k = 0; k < 12; ++k) ok &= R[k] == R[k];
+    return ok;
 }
 
 __device__ __forceinline__ double reproj_err2(const double *Rt, const double K4[4], const float *obj, const float *img)
@@ -248,41 +301,63 @@ struct PnpFrame {
 };
 struct PnpBatch { PnpFrame f[RELOC_BATCH_MAX]; };
 
-// grid (ceil(iters/64), n_cand_max), block 64
+// grid (ceil(iters/64), n_cand_max), block 256: FOUR lanes per hypothesis.  The sampler, the quartic and its resolvent are
+// per hypothesis (the four lanes of a quad compute them in lockstep, same values); each of the <= 4 real roots is then
+// polished, turned into a pose and scored against the fourth sample point by its own lane, and the quad keeps the pose with
+// the smallest error (lowest root on ties: the specification's first-minimum rule).  Rounds 1-2 walked the roots one after
+// the other in one lane: 4 us of an 18 us dependent chain.
+constexpr int HYP_BLOCK = 256;
 __device__ __forceinline__ void pnp_hyp_body(const float *__restrict__ obj, const float *__restrict__ img,
                                              const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                              const PnpParams &prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
 {
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= prm.iters) return;
+    const int h = blockIdx.x * (HYP_BLOCK / 4) + (threadIdx.x >> 2), sol = threadIdx.x & 3;
+    if (h >= prm.iters) return;                                           // quad-uniform, like every exit below
     const int m = m_arr[c];
     const float *o = obj + (size_t)c * prm.stride * 3;
     const float *im = img + (size_t)c * prm.stride * 2;
     double *out = Rt_out + ((size_t)c * MAX_HYP + h) * 12;
     int32_t *cn = cnt + (size_t)c * MAX_HYP + h;
     int idx[4];
-    if (m < prm.min_m || !pnp_sample(prm.seed, h, m, idx)) { *cn = -1; return; }
-    double P[9], xn[6], sols[48];
+    PNP_T(0);
+    if (m < prm.min_m || !pnp_sample(prm.seed, h, m, idx)) { if (sol == 0) *cn = -1; return; }
+    PNP_T(1);
+    double P[9], xn[6], Rt[12];
     for (int k = 0; k < 3; ++k) {
         for (int e = 0; e < 3; ++e) P[3 * k + e] = o[3 * idx[k] + e];
         xn[2 * k] = ((double)im[2 * idx[k]] - prm.K4[2]) / prm.K4[0];
         xn[2 * k + 1] = ((double)im[2 * idx[k] + 1] - prm.K4[3]) / prm.K4[1];
     }
-    const int ns = p3p(P, xn, sols);
-    int best = -1;
-    double beste = 0;
-    for (int s = 0; s < ns; ++s) {
-        const double e = reproj_err2(sols + 12 * s, prm.K4, o + 3 * idx[3], im + 2 * idx[3]);
-        if (!(e == e)) continue;
-        if (best < 0 || e < beste) { best = s; beste = e; }
+    PNP_T(2);
+    P3pSetup S;
+    p3p_setup(P, xn, S);
+    double e = 0;
+    bool valid = p3p_solution(S, P, sol, Rt);
+    if (valid) {
+        e = reproj_err2(Rt, prm.K4, o + 3 * idx[3], im + 2 * idx[3]);
+        valid = e == e;
     }
-    if (best < 0) { *cn = -1; return; }
-    for (int k = 0; k < 12; ++k) out[k] = sols[12 * best + k];
-    *cn = 0;
+    PNP_T(6);
+    // the quad's winner: smallest error, lowest root index on ties
+    int win = valid ? sol : 4;
+    double we = e;
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) {
+        const int ow = __shfl_xor(win, d);
+        const double oe = __shfl_xor(we, d);
+        const bool take = ow < 4 && (win >= 4 || oe < we || (oe == we && ow < win));
+        if (take) { win = ow; we = oe; }
+    }
+    if (win >= 4) { if (sol == 0) *cn = -1; return; }
+    if (sol == win) {
+        for (int k = 0; k < 12; ++k) out[k] = Rt[k];
+        *cn = 0;
+    }
+    PNP_T(7);
 }
-__global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
+__global__ __launch_bounds__(HYP_BLOCK) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
                                                 const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                 PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
 {
@@ -290,7 +365,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float *__restrict__ obj, c
     pnp_hyp_body(obj, img, m_arr, n_cand_p, prm, Rt_out, cnt);
 }
 // grid (ceil(iters/64), n_cand_max, frames)
-__global__ __launch_bounds__(64) void k_pnp_hyp_batch(PnpBatch b, PnpParams prm)
+__global__ __launch_bounds__(HYP_BLOCK) void k_pnp_hyp_batch(PnpBatch b, PnpParams prm)
 {
     RELOC_SMALL_KERNEL_PRIO();
     const PnpFrame &F = b.f[blockIdx.z];
@@ -564,6 +639,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
     // then shrink the cap"), evaluated by the wave: lane l holds the counts of hypotheses l, l+64, ...;
     // each step finds the earliest improving hypothesis below the current cap with ballots.
     int cl[MAX_HYP / 64];
+    PNP_T(8);
 #pragma unroll
     for (int j = 0; j < MAX_HYP / 64; ++j) {
         const int h = j * 64 + lane;
@@ -572,6 +648,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
     int s_best_v = -1;
     if (m >= prm.min_m) {
         int niters = prm.iters, best_count = RELOC_PNP_SAMPLE - 1, pos = 0;
+        const double log_num = ransac_log_num(prm.conf);
         for (;;) {
             int found = -1;
 #pragma unroll
@@ -591,11 +668,12 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
             }
             s_best_v = found;
             best_count = ch;
-            niters = ransac_update_iters(prm.conf, (double)(m - ch) / (double)m, niters);
+            niters = ransac_update_iters(log_num, (double)(m - ch) / (double)m, niters);
             pos = found + 1;
         }
     }
     const int best = s_best_v;
+    PNP_T(9);
     if (best < 0) {
         if (lane == 0) { po.ok = 0; po.n_inl = 0; po.best_h = -1; po.n_matches = m; po.reproj_mean = 0; }
         return;
@@ -613,11 +691,14 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
         n += __popcll(bal);
     }
     __syncthreads();
+    PNP_T(10);
     // Levenberg-Marquardt on the inliers, left-multiplied rotation increment
     double H[21], g[6], Hn[21], gn[6];
     double cost = lm_normal_wave(o, im, inl, n, Rt, prm.K4, H, g);
     double lambda = RELOC_LM_LAMBDA0;
+    PNP_T(11);
     for (int trial = 0; trial < RELOC_LM_MAX_TRIALS; ++trial) {
+        PNP_V(16, trial + 1);
         double A[36], rhs[6], dx[6];
         {
             int oo = 0;
@@ -629,14 +710,18 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
             A[6 * a + a] += lambda * (d > 1e-300 ? d : 1e-300);
             rhs[a] = -g[a];
         }
+        if (trial == 0) PNP_T(17);
         if (!chol_solve6(A, rhs, dx)) { lambda *= 10.0; continue; }
+        if (trial == 0) PNP_T(18);
         double dR[9], Rn[12];
         rodrigues_exp(dx, dR);
         for (int r = 0; r < 3; ++r)
             for (int cc = 0; cc < 3; ++cc)
                 Rn[3 * r + cc] = dR[3 * r] * Rt[cc] + dR[3 * r + 1] * Rt[3 + cc] + dR[3 * r + 2] * Rt[6 + cc];
         for (int k = 0; k < 3; ++k) Rn[9 + k] = Rt[9 + k] + dx[3 + k];
+        if (trial == 0) PNP_T(19);
         const double cn = lm_normal_wave(o, im, inl, n, Rn, prm.K4, Hn, gn);
+        if (trial == 0) PNP_T(20);
         double step = 0;
         for (int a = 0; a < 6; ++a) if (fabs(dx[a]) > step) step = fabs(dx[a]);
         const bool tiny = cn == cn && fabs(cn - cost) <= RELOC_LM_COST_EPS * (cost > 1e-300 ? cost : 1e-300);
@@ -652,6 +737,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
             if (step < RELOC_LM_STEP_EPS || tiny) break;
         }
     }
+    PNP_T(12);
     // mean inlier reprojection error under the refined pose (reference M:353-356)
     double esum = 0;
     for (int kk = lane; kk < n; kk += 64) {
@@ -668,6 +754,8 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
         po.best_h = best;
         po.n_matches = m;
     }
+    PNP_T(13);
+    PNP_V(14, n);
 }
 template <int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_pnp_finish(const float *__restrict__ obj, const float *__restrict__ img,
@@ -714,7 +802,7 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
     }
     const PnpParams prm = make_params(K4, iters, thr_px, conf, seed, MAX_REC_ROWS, min_m);
     reloc_prof_begin(ctx, RELOC_PROF_PNP);
-    hipLaunchKernelGGL(k_pnp_hyp, dim3((iters + 63) / 64, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img,
+    hipLaunchKernelGGL(k_pnp_hyp, dim3((iters + 63) / 64, n_cand_max), dim3(HYP_BLOCK), 0, ctx->stream, ctx->p_obj, ctx->p_img,
                        ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt);
     hipLaunchKernelGGL(k_pnp_score, dim3(iters, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
                        n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, (uint8_t *)nullptr, MAX_HYP);
@@ -748,7 +836,7 @@ int pnp_run_candidates_batch(reloc_ctx *const *ctxs, int n, int n_cand_max, cons
         F.out = c->p_out; F.seed = seeds ? seeds[f < n ? f : 0] : 0;
     }
     reloc_prof_begin(c0, RELOC_PROF_PNP);
-    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3((iters + 63) / 64, n_cand_max, n), dim3(64), 0, c0->stream, b, prm);
+    hipLaunchKernelGGL(k_pnp_hyp_batch, dim3((iters + 63) / 64, n_cand_max, n), dim3(HYP_BLOCK), 0, c0->stream, b, prm);
     hipLaunchKernelGGL(k_pnp_score_batch, dim3(iters, n_cand_max, n), dim3(64), 0, c0->stream, b, prm, MAX_HYP);
     hipLaunchKernelGGL(k_pnp_finish_batch<4>, dim3(n_cand_max, n), dim3(64), 0, c0->stream, b, prm);
     reloc_prof_end(c0, RELOC_PROF_PNP);

@@ -8,6 +8,8 @@
 //   first 5;  global: mutual-match count of every heading-compatible record, top 25) ->
 //   mutual matches of each candidate (reloc_match.hip, emit mode) -> gather 3-D/2-D pairs ->
 //   PnP-RANSAC batch (reloc_pnp.hip) -> gates, pose composition, best by inliers, consistency.
+#include <time.h>
+
 #include "reloc_internal.h"
 
 struct TickParams {
@@ -20,6 +22,7 @@ struct TickParams {
     // matcher parameters (reloc_params)
     int max_candidates, min_matches, min_inliers, global_min_inliers;
     double radius_m, cos_tol, reproj_max_px, global_reproj_max_px, consistency_m;
+    int seq;                  // sequence stamp of this tick (ctx->tick_seq), stored into the host records after their body
 };
 
 __device__ void rot_to_quat(const double R[9], double q[4])
@@ -462,6 +465,13 @@ static void launch_topk_counts(reloc_ctx *ctx, int k, int32_t *out_ids, int32_t 
                        (const int32_t *)ctx->f_count, out_nfeat);
 }
 
+__device__ __forceinline__ void tick_stamp(TickResult *res_host, TickResult *res_ext, int seq)
+{
+    if (!seq) return;
+    __hip_atomic_store(&res_host->pad[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (res_ext) __hip_atomic_store(&res_ext->pad[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- gates, pose composition, best candidate (M:349-410; G:381-382,424) ---------------------------
 // one lane per candidate composes its pose; the best (most inliers, first on ties) is picked by a wave
 // reduction.
@@ -469,7 +479,10 @@ __device__ __forceinline__ void tick_finalize_body(const int32_t *__restrict__ c
                                                    const PnpOut *__restrict__ pnp, const double *__restrict__ db_pose,
                                                    const int32_t *__restrict__ f_count, const TickParams &prm,
                                                    const int32_t *__restrict__ relocating_p, TickResult *__restrict__ res,
-                                                   TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext){
+                                                   TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext, int seq){
+    // seq: after the record's 96 bytes, its last-but-one word (pad[0]) receives the tick's sequence stamp with a system-scope
+    // release store: a host that polls that word (reloc_tick_wait) has the complete record the moment it sees the stamp,
+    // without going through the runtime's stream-completion path.
     // res: the device record (read by the accumulation and by device-side consumers); res_host: the ctx's own record in
     // pinned host memory, what reloc_tick_result() reads after the stream has drained -- the kernel writes it over PCIe
     // itself, which takes a 5 us copy kernel (and its launch) out of every synchronous tick; res_ext: a caller-named pinned
@@ -531,6 +544,7 @@ __device__ __forceinline__ void tick_finalize_body(const int32_t *__restrict__ c
             *res = out;
             *res_host = out;
             if (res_ext) *res_ext = out;
+            tick_stamp(res_host, res_ext, seq);
         }
         return;
     }
@@ -545,6 +559,7 @@ __device__ __forceinline__ void tick_finalize_body(const int32_t *__restrict__ c
         *res = out;
         *res_host = out;
         if (res_ext) *res_ext = out;
+        tick_stamp(res_host, res_ext, seq);
     }
 }
 __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict__ cand_ids, const int32_t *__restrict__ cand_n,
@@ -554,12 +569,13 @@ __global__ __launch_bounds__(64) void k_tick_finalize(const int32_t *__restrict_
                                                       TickResult *__restrict__ res_host, TickResult *__restrict__ res_ext)
 {
     RELOC_SMALL_KERNEL_PRIO();
-    tick_finalize_body(cand_ids, cand_n, pnp, db_pose, f_count, prm, relocating_p, res, res_host, res_ext);
+    tick_finalize_body(cand_ids, cand_n, pnp, db_pose, f_count, prm, relocating_p, res, res_host, res_ext, prm.seq);
 }
 // the finalisation of up to 8 frames in one launch: block = frame; prm carries what the frames share, F.base_pose the rest
 struct FinalFrame {
     const int32_t *cand_ids, *cand_n; const PnpOut *pnp; const int32_t *f_count, *relocating; TickResult *res, *res_host, *res_ext;
     double base_pose[7];
+    int seq;
 };
 struct FinalBatch { FinalFrame f[RELOC_BATCH_MAX]; };
 __global__ __launch_bounds__(64) void k_tick_finalize_batch(FinalBatch b, const double *__restrict__ db_pose, TickParams prm)
@@ -567,7 +583,7 @@ __global__ __launch_bounds__(64) void k_tick_finalize_batch(FinalBatch b, const 
     RELOC_SMALL_KERNEL_PRIO();
     const FinalFrame &F = b.f[blockIdx.x];
     for (int k = 0; k < 7; ++k) prm.base_pose[k] = F.base_pose[k];
-    tick_finalize_body(F.cand_ids, F.cand_n, F.pnp, db_pose, F.f_count, prm, F.relocating, F.res, F.res_host, F.res_ext);
+    tick_finalize_body(F.cand_ids, F.cand_n, F.pnp, db_pose, F.f_count, prm, F.relocating, F.res, F.res_host, F.res_ext, F.seq);
 }
 
 
@@ -588,10 +604,18 @@ static TickParams make_tick_params(reloc_ctx *ctx, const double base_pose[7], in
     p.global_min_inliers = q.global_min_inliers;
     p.radius_m = q.candidate_radius_m; p.cos_tol = heading_cos_tol_host(ctx); p.reproj_max_px = q.reproj_max_px;
     p.global_reproj_max_px = q.global_reproj_max_px; p.consistency_m = q.consistency_m;
+    p.seq = 0;
     return p;
 }
 
 __global__ void k_set_flag(int32_t *flag, int v) { *flag = v; }
+
+// the stamp of the tick being enqueued: 1, 2, ... (never 0: 0 means "no stamp")
+static int tick_next_seq(reloc_ctx *ctx)
+{
+    ctx->tick_seq = ctx->tick_seq >= 0x7fffffff ? 1 : ctx->tick_seq + 1;
+    return ctx->tick_seq;
+}
 
 static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
 {
@@ -612,8 +636,10 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
                                 ctx->prm.ransac_confidence, seed, ctx->prm.min_matches);
     ctx->latency_shapes = false;
     if (rc) return rc;
+    TickParams fin = prm;
+    fin.seq = tick_next_seq(ctx);
     hipLaunchKernelGGL(k_tick_finalize, dim3(1), dim3(64), 0, st, ctx->cand_ids, ctx->cand_n, ctx->p_out, ctx->db_pose,
-                       ctx->f_count, prm, ctx->tick_flags, ctx->tick_res, ctx->tick_res_host, ctx->tick_res_ext);
+                       ctx->f_count, fin, ctx->tick_flags, ctx->tick_res, ctx->tick_res_host, ctx->tick_res_ext);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }
@@ -701,6 +727,7 @@ static int tick_solve_batch(reloc_ctx *const *ctxs, int n, const double *base_po
         F.cand_ids = c->cand_ids; F.cand_n = c->cand_n; F.pnp = c->p_out; F.f_count = c->f_count; F.relocating = c->tick_flags;
         F.res = c->tick_res; F.res_host = c->tick_res_host; F.res_ext = res_ext_base ? res_ext_base + g : c->tick_res_ext;
         for (int k = 0; k < 7; ++k) F.base_pose[k] = base_poses[7 * g + k];
+        F.seq = f < n ? tick_next_seq(c) : 0;
     }
     hipLaunchKernelGGL(k_tick_finalize_batch, dim3(n), dim3(64), 0, c0->stream, b, c0->db_pose, prm);
     HIP_TRY(hipGetLastError());
@@ -761,11 +788,37 @@ RELOC_API int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t 
     return tick_solve_batch(ctxs, n, base_poses, global_reloc, -1, seeds, nullptr);
 }
 
+// Waits for the result record of the LAST tick enqueued on this context by polling its sequence stamp in pinned host memory
+// (written by the tick's last kernel behind the record's body).  The runtime's own completion path (hipStreamSynchronize:
+// completion signal, and after an idle period an interrupt) costs tens of microseconds more than the store is late; after
+// 20 ms without the stamp this falls back to it.  Does NOT wait for work enqueued behind the tick.
+RELOC_API int reloc_tick_wait(reloc_ctx *ctx)
+{
+    ARG_CHECK_CTX(ctx, true, "ctx is NULL");
+    const int want = ctx->tick_seq;
+    if (want == 0 || !ctx->tick_res_host) { HIP_TRY(hipStreamSynchronize(ctx->stream)); return RELOC_OK; }
+    volatile int32_t *stamp = (volatile int32_t *)&ctx->tick_res_host->pad[0];
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spin = 1;; ++spin) {
+        if (*stamp == want) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return RELOC_OK; }
+        __builtin_ia32_pause();
+        if ((spin & 0x3FF) == 0) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 20000000ll) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (*stamp != want) { reloc_set_error("reloc_tick_wait: the stream drained without the tick's result record (a tick that failed to enqueue?)"); return RELOC_E_STATE; }
+    return RELOC_OK;
+}
+
 RELOC_API int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj, int32_t *lm_idx,
                                 int32_t *outcome, int32_t *n_candidates)
 {
     ARG_CHECK_CTX(ctx, true, "ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    { const int rc = reloc_tick_wait(ctx); if (rc) return rc; }
     const TickResult r = *ctx->tick_res_host;          // written by k_tick_finalize itself (pinned, device-visible)
     if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
     if (n_inl) *n_inl = r.n_inl;
@@ -789,7 +842,7 @@ RELOC_API int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_
                                    int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating)
 {
     ARG_CHECK_CTX(ctx, true, "ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    { const int rc = reloc_tick_wait(ctx); if (rc) return rc; }
     const TickResult r = *ctx->tick_res_host;          // written by k_tick_finalize itself (pinned, device-visible)
     if (anchor_pose) for (int k = 0; k < 7; ++k) anchor_pose[k] = r.anchor_pose[k];
     if (n_inl) *n_inl = r.n_inl;

@@ -64,6 +64,10 @@ class Engine:
     def sync(self):
         N.check(self._lib.reloc_sync(self._ctx), "reloc_sync")
 
+    def tick_wait(self):
+        """wait for the result record of the last tick enqueued (polls its sequence stamp in pinned memory: reloc_tick_wait)"""
+        N.check(self._lib.reloc_tick_wait(self._ctx), "reloc_tick_wait")
+
     def dev_alloc(self, nbytes: int) -> int:
         p = self._lib.reloc_dev_alloc(self._ctx, int(nbytes))
         if not p:

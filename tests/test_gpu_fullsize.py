@@ -373,3 +373,62 @@ def test_whole_tick_at_config_2_and_3_size(engine, records, w, h):
                 assert np.abs(np.array(got.anchor_pose) - np.array(exp.anchor_pose)).max() < 1e-4
             published += exp.published
     assert published >= 4
+
+
+def test_whole_tick_at_config_3_size_against_the_oracle(engine, oracle):
+    """BASELINE.json config 3 (10 000 records, 1280x720), whole-database relocalisation tick: the expected values come from
+    the host core running on the CPU ORACLE (tests/oracle_backend.py: oracle ORB, the oracle's mutual matcher over ALL 10 000
+    records, oracle PnP), not from the HIP shim -- the fused device tick must reproduce outcome, candidate count, inlier
+    count and winning record exactly, reprojection error and anchor pose within 1e-4."""
+    from oracle_backend import oracle_cv2
+    from nclt_slam_project_amd import landmarks as LM
+    from nclt_slam_project_amd.matcher import FusedLandmarkMatcher, LandmarkMatcherCore, MatcherConfig
+    w, h = 1280, 720
+    frames, db, base_poses = _workload(engine, 10000, w, h, n_frames=2)
+    data = LM.new_database(LM.unpack_landmarks(*db), width=w, height=h)
+    cfg = dict(accum_enable=False)
+    fused = FusedLandmarkMatcher(data, engine=engine, config=MatcherConfig(global_reloc=True, **cfg))
+    core = LandmarkMatcherCore(data, cv2=oracle_cv2(), config=MatcherConfig(global_reloc=True, reloc_age_s=-1.0, reloc_drift_m=-1.0, **cfg))
+    published = 0
+    for f, (img, bp) in enumerate(zip(frames, base_poses)):
+        far = (bp[0], bp[1] + 30.0, *bp[2:])                  # no local candidate: the whole-database search decides
+        exp = core.tick(img, None, far, ts=1000.0 + f, drift_est=10.0)
+        got = fused.tick(img, far, ts=1000.0 + f, drift_est=10.0)
+        fused.last_anchor_ts = 0.0
+        assert (got.outcome, got.n_candidates, got.n_inliers, got.relocating) == \
+               (exp.outcome, exp.n_candidates, exp.n_inliers, exp.relocating), (f, got, exp)
+        assert exp.relocating and exp.n_candidates == 25
+        if exp.anchor_pose:
+            assert got.lm_idx == exp.lm_idx
+            assert abs(got.reproj_err - exp.reproj_err) < 1e-4
+            assert np.abs(np.array(got.anchor_pose) - np.array(exp.anchor_pose)).max() < 1e-4
+        published += exp.published
+    assert published == 2
+
+
+def test_selftest_harness_through_the_hip_shim(engine, oracle):
+    """checkpoint_a_selftest's protocol (S:44-48, 66-71: knnMatch with query = CURRENT descriptors, train = teach record,
+    Lowe 0.80, then PnP) driven through the HIP cv2 shim, row for row equal to the same run on the oracle backend"""
+    from oracle_backend import oracle_cv2
+    from nclt_slam_project_amd.cv2_shim import Cv2Shim
+    from nclt_slam_project_amd.recorder import LandmarkRecorderCore
+    from nclt_slam_project_amd.selftest import selftest
+    scene = synth.WallScene()
+    out = {}
+    for name, cv2 in (("oracle", oracle_cv2()), ("hip", Cv2Shim(engine))):
+        rec = LandmarkRecorderCore(cv2=cv2)
+        frames = []
+        for x in (2.0, 4.5, 7.0, 9.5, 12.0):
+            bp = synth.base_pose(x, 0.0, 0.0)
+            bgr, dep = scene.render(bp)
+            if rec.tick(bgr, dep, bp, x) is not None:
+                frames.append(bgr)
+        out[name] = (selftest([(f, i) for i, f in enumerate(frames)], rec.database(), cv2), rec)
+    (ok_o, s_o), rec_o = out["oracle"]
+    (ok_h, s_h), rec_h = out["hip"]
+    assert ok_o and ok_h and s_h["n"] == s_o["n"] >= 4 and s_h["n_within"] == s_o["n_within"] == s_o["n"]
+    for a, b in zip(rec_h.landmarks, rec_o.landmarks):       # the taught records themselves are identical
+        assert np.array_equal(a["descriptors"], b["descriptors"]) and np.array_equal(a["keypoints_3d_cam"], b["keypoints_3d_cam"])
+    for rh, ro in zip(s_h["rows"], s_o["rows"]):
+        assert rh[:3] == ro[:3], (rh, ro)                    # sample, winning record, inlier count
+        assert abs(rh[3] - ro[3]) < 1e-4 and abs(rh[4] - ro[4]) < 1e-4, (rh, ro)

@@ -15,8 +15,8 @@ python tools/pmc_summarize.py $P $P/summary.json > /dev/null || true
 echo pmc done
 timeout -k 10 500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ingest > $O/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-matrix > $O/stats1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-2hz --no-extra-scans > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-matrix --no-2hz --no-extra-scans > $O/stats1.log 2>&1
 timeout -k 10 300 python bench.py --streams 1 --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_1stream.json
 timeout -k 10 300 python bench.py --size 720p --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_720p.json
 timeout -k 10 400 python tools/microbench.py > $O/microbench.jsonl 2>$O/microbench.err || true
