@@ -191,10 +191,10 @@ def cpu_baseline(frames, db, n_frames=112, n_warm=16):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r2/summary.json, else pmc_r1e: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r3/summary.json, else pmc_r2 / pmc_r1e: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, handled as MI355X_MICROARCH.md's HBM section prescribes); None if absent."""
     d = None
-    for rnd in ("pmc_r2", "pmc_r1e"):
+    for rnd in ("pmc_r3", "pmc_r2", "pmc_r1e"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))[kernel]
             break
@@ -204,7 +204,10 @@ def pmc_traffic(kernel):
         return None
     # streaming 16-B/lane pattern (matrix kernel): FETCH_SIZE is doubled, WRITE_SIZE exact; the scan kernel reads through
     # scalar loads, for which the counter is uncalibrated: its raw value is used (lower bound)
-    return d["hbm_bytes_upper"] if kernel == "k_hamming_matrix" else d["hbm_bytes_lower"]
+    if "hbm_bytes_upper" not in d:
+        return None
+    # 16-byte-per-lane streaming reads (matrix kernel, few-query scan): FETCH_SIZE doubled; scalar-load reads (k_db_scan): raw
+    return d["hbm_bytes_lower"] if kernel == "k_db_scan" else d["hbm_bytes_upper"]
 
 
 def scan_case(e, L, rows, Qs, seed, forms=(False, True), n=40, preroll=30):
@@ -283,15 +286,23 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
         # batch; DEPTH batches in flight, each on its own stream
         sr = DeviceShardedRelocalizer(shard, rank, world, torch.device("cuda", local_rank), batch=BATCH, depth=DEPTH)
 
+        flight = []                                                       # batches in flight, ACROSS steps: a step that drained its
+                                                                          # own batches would empty the device once per step (round 3,
+                                                                          # first form: 5336 frames/s at 10k records; the frames of a
+                                                                          # stream do not wait for a step boundary)
+        last_out = [None]
+
         def step(s0):
-            out, flight = None, []
             for i in range(0, B, BATCH):
                 flight.append(sr.submit(frames_dev, base_poses, [s0 + i + j for j in range(BATCH)]))
                 if len(flight) >= DEPTH:
-                    out = sr.result(flight.pop(0))[-1]
-            for b in flight:
-                out = sr.result(b)[-1]
-            return out
+                    last_out[0] = sr.result(flight.pop(0))[-1]            # every batch's results are collected, the oldest first
+            return last_out[0]
+
+        def drain():
+            while flight:
+                last_out[0] = sr.result(flight.pop(0))[-1]
+            return last_out[0]
     else:
         hr = ShardedRelocalizer(shard, shard.base, rank, world, device=dev)
 
@@ -301,8 +312,12 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
                 out = hr.tick_batch(frames_dev, base_poses, seeds=[s0 + i + j for j in range(BATCH)])[-1]
             return out
 
+        def drain():
+            return None
+
     for w_ in range(args.warmup + 3):
         step(0)
+    drain()
     e.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -311,6 +326,7 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
     last = None
     for k in range(args.steps):
         last = step(k * B)
+    last = drain() or last                                                # the timed region ends when every frame's result is on the host
     e.sync()
     torch.cuda.synchronize()
     if dist is not None:
@@ -667,6 +683,8 @@ def main():
                                    note="teach databases of the reference are ragged, ~45-100 rows per record (routes/01_road/teach/README.md:57,75); "
                                         "VALU-bound like the headline kernel: compare valu.pairs_per_s")
             sq = scan_case(ex, 100000, "fixed64", (1, 8, 32), SEED + 12)
+            for r_ in sq:
+                r_["traffic"] = pmc_traffic({1: "k_db_scan_rows_q1", 8: "k_db_scan_rows_q8"}.get(r_["Q"], "-"))
             roofline_small_q = dict(sq[0], workload="100000 records x 64 rows (205 MB), Q = 1: the variant-G scan shape with few current descriptors "
                                                     "(G:329-344), the HBM-bound match shape", by_Q={str(r["Q"]): r for r in sq})
             ex.close()

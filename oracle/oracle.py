@@ -46,8 +46,8 @@ def select(fast: bool):
     global _lib
     key = "fast" if fast else "strict"
     if key not in _libs:
-        if fast and not os.path.exists(_FAST_PATH):
-            build_fast()
+        if fast:
+            build_fast()      # always, once per process: -march=native is for THIS machine, and a copy that travelled here may be stale
         _libs[key] = _load(_FAST_PATH if fast else build())
     _lib = _libs[key]
 

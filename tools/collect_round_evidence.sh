@@ -1,9 +1,12 @@
 # Collects the judged evidence of a round on the GPU box (run through gpurun; writes under gpurun_out/<round>/, the
-# summaries are copied into profiles/ by hand afterwards).   usage: bash tools/collect_round_evidence.sh r2
+# summaries are copied into profiles/ by tools/copy_round_evidence.sh afterwards).
+#   usage: bash tools/collect_round_evidence.sh r3 [part]      part: all (default) | core | extra
 set -e
-R=${1:-r2}
+R=${1:-r3}; PART=${2:-all}
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 O=gpurun_out/$R; mkdir -p $O
+NOX="--no-cpu-baseline --no-ingest --no-2hz --no-extra-scans"
+if [ $PART = all ] || [ $PART = core ]; then
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $O/gputest.log 2>&1 || true
 tail -2 $O/gputest.log
 P=$O/pmc; mkdir -p $P
@@ -13,24 +16,29 @@ timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WA
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_SALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $P/sq2 -o sq2 -- python3 tools/pmc_target.py > $P/sq2.log 2>&1
 python tools/pmc_summarize.py $P $P/summary.json > /dev/null || true
 echo pmc done
-timeout -k 10 500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
+timeout -k 10 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 echo bench done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-2hz --no-extra-scans > $O/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-cpu-baseline --no-ingest --no-matrix --no-2hz --no-extra-scans > $O/stats1.log 2>&1
-timeout -k 10 300 python bench.py --streams 1 --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_1stream.json
-timeout -k 10 300 python bench.py --size 720p --steps 30 --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_720p.json
-timeout -k 10 400 python tools/microbench.py > $O/microbench.jsonl 2>$O/microbench.err || true
-# variant / experiment logs that DESIGN.md cites (developer harnesses; each a few seconds)
-if [ -x tools/exp_matrix2 ]; then
-  EXP_COMPUTE=1 timeout -k 10 300 ./tools/exp_matrix2 > $O/exp_matrix2_chains.log 2>&1 || true
-  EXP_SPACING=1 timeout -k 10 300 ./tools/exp_matrix2 > $O/exp_matrix2_spacing.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 $NOX > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-matrix $NOX > $O/stats1.log 2>&1
+# the matrix kernel: trace of bench.py --matrix-only (400 pre-roll + 1 warm-up + 100 timed launches), statistics of the TIMED tail only
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/mtrace -o matrix -- python3 bench.py --matrix-only --steps 100 --warmup 1 > $O/matrix_trace_bench.json 2>$O/mtrace.err
+python tools/kernel_trace_tail.py $O/mtrace k_hamming_matrix 100 > $O/matrix_timed_only.json || true
+rm -rf $O/mtrace
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || true
+echo core done
 fi
-timeout -k 10 120 python tools/exp_matrix_prod.py > $O/matrix_prod_series.log 2>&1 || true
+if [ $PART = all ] || [ $PART = extra ]; then
+timeout -k 10 300 python bench.py --streams 1 --steps 30 --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_1stream.json
+timeout -k 10 300 python bench.py --size 720p --steps 30 --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_720p.json
+timeout -k 10 300 python bench.py --batch 8 --steps 60 --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_batch8.json
+timeout -k 10 300 python bench.py --rows ragged --steps 60 --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_rows_ragged.json
+timeout -k 10 400 python tools/microbench.py > $O/microbench.jsonl 2>$O/microbench.err || true
 timeout -k 10 300 python tools/exp_stage_throughput.py 4 > $O/stage_throughput.log 2>&1 || true
 timeout -k 10 400 python bench.py --shard-db --records 100000 --steps 10 2>/dev/null | tail -1 > $O/bench_shard100k.json || true
 timeout -k 10 300 python bench.py --shard-db --steps 30 2>/dev/null | tail -1 > $O/bench_shard10k.json || true
 timeout -k 10 300 python bench.py --matrix-only --steps 200 2>/dev/null | tail -1 > $O/bench_matrix_only.json || true
 # the multi-rank code paths with two ranks on this ONE GPU (gloo; not a scaling number)
-timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --backend gloo --rehearse --no-cpu-baseline --no-matrix 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_rehearsal.json || true
-timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || true
+timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --backend gloo --rehearse --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_rehearsal.json || true
+echo extra done
+fi
 echo collected

@@ -1,0 +1,5 @@
+# Developer harness: the 4-stream frame benchmark against the number of scan-workgroup generations (RELOC_SCAN_GENS), interleaved.
+for g in 3 2 3 2 4 1; do
+  echo -n "gens=$g  "
+  RELOC_SCAN_GENS=$g timeout -k 10 120 python bench.py --steps 60 --no-cpu-baseline --no-matrix --no-ingest --no-2hz --no-extra-scans 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'frames/s  scan alone', round(d['stage_us']['db_scan_per_frame'],1), 'in-config scan', round(d['roofline']['in_config']['scan_avg_launch_us'],1))"
+done

@@ -16,7 +16,7 @@ O.build()
 e = Engine(0, 1280, 720, 8192)
 rng = np.random.default_rng(args.seed)
 t_end = time.time() + args.seconds
-n_case = {"match": 0, "knn": 0, "db": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
+n_case = {"match": 0, "knn": 0, "db": 0, "db_small": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
 
 
 def descs(n, dup_p=0.1, low_entropy=False):
@@ -66,6 +66,18 @@ while time.time() < t_end:
         else:
             ratio = float(rng.choice([0.7, 0.75, 0.8, 0.9, 1.0]))
             if not np.array_equal(e.db_ratio_counts(cur, ratio), O.db_ratio_counts(db, off, cur, ratio)): fail(kind, (L, Q, ratio))
+    elif kind == "db_small":      # the lane-per-teach-row kernel (<= 64 current descriptors): 4- / 8- / 16-query groups, records of
+        L = int(rng.integers(1, 400)); Q = int(rng.integers(1, 65))          # 0 .. 1100 rows (> 1024 rows: the column kernel takes over)
+        n = rng.integers(0, 140, L); n[rng.integers(0, L)] = int(rng.integers(0, 1100))
+        if rng.random() < 0.3: n[:] = 64
+        off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
+        le = rng.random() < 0.4
+        cur = descs(Q, low_entropy=le); db = descs(max(int(off[-1]), 1), low_entropy=le)[: int(off[-1])]
+        if len(db) and rng.random() < 0.7:
+            r = int(rng.integers(0, L)); k = int(min(n[r], Q))
+            if k: db[off[r]:off[r] + k] = synth.perturb_descriptors(rng, cur[rng.choice(Q, k, replace=False)], 0.05)
+        e.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
+        if not np.array_equal(e.db_match_counts(cur), O.db_match_counts(db, off, cur)): fail(kind, (L, Q, le))
     elif kind == "matrix":
         na, nb = int(rng.integers(1, 300)), int(rng.integers(1, 5000))
         a, b = descs(na), descs(nb)
@@ -88,11 +100,14 @@ while time.time() < t_end:
         stride = 3 * w + int(rng.choice([0, 0, 1, 2, 3, 4, 13]))
         raw = np.zeros((h, stride), np.uint8); raw[:, :3 * w] = img.reshape(h, 3 * w)
         order = bool(rng.integers(0, 2))
+        bits = int(rng.choice([14, 14, 15]))                              # reloc_params.gray_coeff_bits
         dev = e.dev_alloc(raw.nbytes)
         e.h2d(dev, raw)
+        e.set_params(gray_coeff_bits=bits)
         n = e.orb_frame_dev(dev, w, h, stride, order_rgb=order)
+        e.set_params(gray_coeff_bits=14)
         e.dev_free(dev)
-        gray = O.gray_u8(img, order)
+        gray = O.gray_u8(img, order, bits)
         pyr = O.pyramid(gray)
         for l in range(8):
             if not np.array_equal(e.frame_debug_plane(0, l), pyr[l]): fail(kind, (w, h, stride, order, "level", l))
