@@ -275,7 +275,9 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
     e = Engine(local_rank, W, H, 2048)
     frames, db, base_poses = build_workload(e, args.records, args.rows, 8)
     BATCH = 8
-    DEPTH = int(os.environ.get("BENCH_SHARD_DEPTH", "8"))         # batches the host runs ahead of the device, on four streams
+    DEPTH = int(os.environ.get("BENCH_SHARD_DEPTH", "16"))        # batches the host runs ahead of the device, on four streams
+                                                                  # (a multiple of 4; 8: 5 500-6 360 frames/s from run to run,
+                                                                  # 16 / 32: 6 370, profiles/r3_shard_repeat.log)
     dev = None if (dist is None or args.backend != "nccl") else torch.device("cuda", local_rank)
     device_path = world == 1 or args.backend == "nccl"
     shard = HipShard(e, *db, rank=rank, world=world, w=W, h=H, n_slots=1 if device_path else BATCH)

@@ -463,8 +463,23 @@ __device__ __forceinline__ void fast_nms_tile(const OrbTable *__restrict__ tab, 
         const int ry = i / (FT + 2), rx = i % (FT + 2);
         const int gy = y0 + ry - 1, gx = x0 + rx - 1;
         int pol = 0;
-        if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3)
-            pol = fast_is_corner(s_img + (ry + 3) * IS + (rx + 3), IS, RELOC_FAST_THRESHOLD);
+        // The usual compass pretest, as a WAVE decision: an arc of 9 of the 16 ring pixels contains at least two of the four
+        // compass pixels (ring positions 0, 4, 8, 12), so a pixel with fewer than two brighter and fewer than two darker
+        // compass pixels is no corner.  Lanes cannot skip work on their own, but a wave whose 64 pixels all fail (flat
+        // ground, sky, the inside of uniform shapes) skips the 16-pixel segment test altogether; the outcome is the same.
+        bool cand = false;
+        const uint8_t *pc = s_img + (ry + 3) * IS + (rx + 3);
+        const bool inside = i < (FT + 2) * (FT + 2) && gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3;
+        if (inside) {
+            const int c = pc[0];
+            const int v0 = (int)pc[3 * IS] - c, v4 = (int)pc[3] - c, v8 = (int)pc[-3 * IS] - c, v12 = (int)pc[-3] - c;
+            const int nb = (v0 > RELOC_FAST_THRESHOLD) + (v4 > RELOC_FAST_THRESHOLD) + (v8 > RELOC_FAST_THRESHOLD) + (v12 > RELOC_FAST_THRESHOLD);
+            const int nd = (v0 < -RELOC_FAST_THRESHOLD) + (v4 < -RELOC_FAST_THRESHOLD) + (v8 < -RELOC_FAST_THRESHOLD) + (v12 < -RELOC_FAST_THRESHOLD);
+            cand = nb >= 2 || nd >= 2;
+        }
+        if (__any(cand)) {
+            if (cand) pol = fast_is_corner(pc, IS, RELOC_FAST_THRESHOLD);
+        }
         s_sc[ry * SS + rx] = 0;
         if (pol) s_corner[atomicAdd(&s_nc, 1)] = (unsigned short)((ry << 6) | rx | (pol < 0 ? 0x8000 : 0));
     }

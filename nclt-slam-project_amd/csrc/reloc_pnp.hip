@@ -640,10 +640,12 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
     // each step finds the earliest improving hypothesis below the current cap with ballots.
     int cl[MAX_HYP / 64];
     PNP_T(8);
+    const int nj = (prm.iters + 63) >> 6;          // registers that hold hypotheses at all (200 iterations: 4 of 16): wave-uniform
 #pragma unroll
     for (int j = 0; j < MAX_HYP / 64; ++j) {
         const int h = j * 64 + lane;
-        cl[j] = h < prm.iters ? cnt[(size_t)c * MAX_HYP + h] : -1;
+        cl[j] = -1;
+        if (j < nj && h < prm.iters) cl[j] = cnt[(size_t)c * MAX_HYP + h];
     }
     int s_best_v = -1;
     if (m >= prm.min_m) {
@@ -653,9 +655,11 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
             int found = -1;
 #pragma unroll
             for (int j = 0; j < MAX_HYP / 64; ++j) {
-                const int h = j * 64 + lane;
-                const unsigned long long bal = __ballot(h >= pos && h < niters && cl[j] > best_count);
-                if (found < 0 && bal) found = j * 64 + __ffsll((long long)bal) - 1;
+                if (j < nj && found < 0) {                               // wave-uniform: the walk stops at the first hit
+                    const int h = j * 64 + lane;
+                    const unsigned long long bal = __ballot(h >= pos && h < niters && cl[j] > best_count);
+                    if (bal) found = j * 64 + __ffsll((long long)bal) - 1;
+                }
             }
             if (found < 0) break;
             // `found` is wave-uniform: read the winner's count with v_readlane instead of four ds_bpermute
@@ -663,8 +667,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
             int ch = 0;
 #pragma unroll
             for (int j = 0; j < MAX_HYP / 64; ++j) {
-                const int cj = __builtin_amdgcn_readlane(cl[j], fl);
-                if (j == fj) ch = cj;
+                if (j == fj) ch = __builtin_amdgcn_readlane(cl[j], fl);    // wave-uniform branch
             }
             s_best_v = found;
             best_count = ch;

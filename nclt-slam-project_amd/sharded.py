@@ -297,18 +297,23 @@ class DeviceShardedRelocalizer:
                     e.set_params_from(e0)
                     e.set_stream(ts.cuda_stream)
                     engines.append(e)
+            # what the host reads of a batch -- every rank's result records, the winners, the feature counts -- is ONE
+            # contiguous device buffer (the tensors below are views of it) and ONE copy into pinned memory per batch
+            n_res, n_win, n_nf = world * B * 96, B * k * 4, B * 4
+            pack = torch.zeros(n_res + n_win + n_nf, dtype=torch.uint8, device=device)
+            h_pack = torch.empty(n_res + n_win + n_nf, dtype=torch.uint8).pin_memory()
+            all_res = pack[:n_res].view(world, B, 96)
             self.groups.append(dict(
                 stream=ts, engines=engines,
                 scan=torch.full((B, row), -1, dtype=torch.int32, device=device),
                 all_scan=torch.empty((world, B, row), dtype=torch.int32, device=device),
-                win_gid=torch.empty((B, k), dtype=torch.int32, device=device),
+                win_gid=pack[n_res:n_res + n_win].view(torch.int32).view(B, k),
                 cand_local=torch.empty((B, k), dtype=torch.int32, device=device),
-                n_feat=torch.empty((B,), dtype=torch.int32, device=device),
-                res=torch.zeros((B, 96), dtype=torch.uint8, device=device),
-                all_res=torch.empty((world, B, 96), dtype=torch.uint8, device=device),
-                h_res=torch.empty((world, B, 96), dtype=torch.uint8).pin_memory(),
-                h_win=torch.empty((B, k), dtype=torch.int32).pin_memory(),
-                h_nfeat=torch.empty((B,), dtype=torch.int32).pin_memory(),
+                n_feat=pack[n_res + n_win:].view(torch.int32),
+                all_res=all_res, pack=pack, h_pack=h_pack,
+                h_res=h_pack[:n_res].view(world, B, 96),
+                h_win=h_pack[n_res:n_res + n_win].view(torch.int32).view(B, k),
+                h_nfeat=h_pack[n_res + n_win:].view(torch.int32),
                 event=torch.cuda.Event(), pending=None))
         self._next = 0
         if bases is None:
@@ -359,23 +364,18 @@ class DeviceShardedRelocalizer:
             if eng is not None:
                 eng.shard_merge_dev(all_scan.data_ptr(), self.world, stride, n, k, sh.base, sh.n_records, g["win_gid"].data_ptr(),
                                     g["cand_local"].data_ptr(), g["n_feat"].data_ptr())
-                res = g["all_res"][self.rank] if self.world > 1 else g["res"]
+                res = g["all_res"][self.rank]
                 Engine.shard_solve_batch_dev(g["engines"][:n], g["cand_local"].data_ptr(), k, base_poses, seeds, res.data_ptr())
             else:
                 wg, _, nf = merge_topk_tensor(all_scan.view(self.world, self.B, row)[:, :n], k, sh.base, 0)
                 g["win_gid"][:n] = wg; g["n_feat"][:n] = nf
-                res = g["all_res"][self.rank] if self.world > 1 else g["res"]
+                res = g["all_res"][self.rank]
                 res.zero_()
                 res.view(torch.int32)[:, 18] = 2                  # outcome no_candidates, never picked
             if self.world > 1:
                 # in place: every rank's own records already sit in its slice of all_res
                 self._all_gather(g["all_res"], g["all_res"][self.rank].clone(), g["stream"])
-                all_res = g["all_res"]
-            else:
-                all_res = g["res"][None]
-            g["h_res"][:all_res.shape[0]].copy_(all_res, non_blocking=True)       # the one trip to the host, not waited for here
-            g["h_win"].copy_(g["win_gid"], non_blocking=True)
-            g["h_nfeat"].copy_(g["n_feat"], non_blocking=True)
+            g["h_pack"].copy_(g["pack"], non_blocking=True)                      # the one trip to the host, not waited for here
             g["event"].record(g["stream"])
         b = _Batch(g, n)
         g["pending"] = b
