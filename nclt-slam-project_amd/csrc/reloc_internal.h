@@ -268,6 +268,7 @@ struct reloc_ctx {
                                      // many workgroups, < 0 static default grid, 0 ticket scheduling
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
     int scan_batch_gens = 0;         // RELOC_SCAN_BATCH_GENS (developer switch): generations of a batched scan launch
+    int scan_quota_rows = 1;         // RELOC_SCAN_QUOTA_ROWS (developer switch): 1 = workgroup budgets in rows + sweepers, 0 = a quota of records (rounds 2-3a)
     int scan_nw = 0;                 // RELOC_SCAN_NW (developer switch): waves per record of the whole-database scan (1, 2, 4); 0 = by shape
     uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 

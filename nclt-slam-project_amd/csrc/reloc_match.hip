@@ -485,9 +485,18 @@ template <int NJ, int NW>
 __device__ __forceinline__ void db_count_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
-    int32_t *__restrict__ counts, const ScanMask &mask, u32 *ticket, int quota, u32 *ticket_pool = nullptr,
+    int32_t *__restrict__ counts, const ScanMask &mask, u32 *ticket, int quota, int n_bounded, u32 *ticket_pool = nullptr,
     int pool_frames = 1, int block = -1, int n_blocks = -1)
 {
+    // quota / n_bounded: the first n_bounded workgroups of a scan leave once they have served `quota` ROWS (their slots go to
+    // whatever waits: with several contexts on the chip another stream's ORB / PnP kernel); their budgets add up to the whole
+    // database, so they normally serve every record.  The eight workgroups behind them (one per XCD, the last to start) draw
+    // until the counters run dry: whatever the budgets left over is served (nothing, when the host knew the row total).
+    // Rounds 2-3a dealt a quota of RECORDS (n_bounded < 0 still does, RELOC_SCAN_QUOTA_ROWS=0): on ragged databases a workgroup
+    // that drew four long records outlived its generation -- N(60,25) rows, scan alone 180 us against 156 us in one generation;
+    // with row budgets 167 us, and the 4-stream run on 64-row records 6 700 against 6 650 frames/s (on ragged records 6 360
+    // against 6 450).  Measured and dropped on the way (profiles/r3_scan_quota.log): a whole last generation without a budget
+    // balances the tail best (163 us) but holds its slots for a third of the scan, 4 streams lose 5 %; one sweeper per CU: 2.5 %.
     if (!ticket_pool) ticket_pool = ticket;
     if (block < 0) { block = blockIdx.x; n_blocks = gridDim.x; }
     constexpr int CB = 64 * NJ;
@@ -539,21 +548,22 @@ __device__ __forceinline__ void db_count_body(
         }
     };
     int it = stand_down ? n_ids : block;
-    int left = quota > 0 ? quota : 0x7fffffff;
+    const bool by_rows = n_bounded >= 0;                                      // n_bounded < 0: a quota of RECORDS for every workgroup
+    int left = (quota > 0 && (!by_rows || block < n_bounded)) ? quota : 0x7fffffff;   // rows (records) this workgroup may still take on
     for (int i = tid; i < ncb * CB; i += 64 * NW) colbuf[i] = 0xFFFFFFFFu;
     if (tid == 0) wsum[0] = wsum[1] = 0;
     __syncthreads();
     int p = 0;
     while (it < n_ids) {
-        --left;
-        u32 next_ticket = 0;
-        if (ticket && tid == 0 && left > 0) next_ticket = draw();        // no draw that this workgroup would not serve
         u32 *colbest = colbuf + p * ncb * CB;
         const int r = rec_ids ? rec_ids[it] : it;
         const bool scored = !(mask.xyh && !heading_ok(mask.xyh + 4 * (int64_t)r, hc, hs, cos_tol));      // workgroup-uniform
         const int64_t row0 = off[r];
         const int n = scored ? (int)(off[r + 1] - row0) : 0;
         const uint4 *rec = db + 2 * row0;
+        left -= by_rows ? max(n, 1) : 1;
+        u32 next_ticket = 0;
+        if (ticket && tid == 0 && left > 0) next_ticket = draw();        // no draw that this workgroup would not serve
         if (n > 0 && C > 0) {
             if (ncb > 1) {                                               // several waves write one row's key: atomic minima
                 for (int i = tid; i < n; i += 64 * NW) rowkey[i] = 0xFFFFFFFFu;
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
     int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota)
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota, int n_bounded)
 {
     extern __shared__ u32 lds[];
     if constexpr (EMIT) RELOC_SMALL_KERNEL_PRIO();          // the emit pass of a few candidates is one of the tick's small kernels
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
         db_scan_body<NJ, true, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
                                    emit_stride, mask, ticket, quota);
     else
-        db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota);
+        db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota, n_bounded);
 }
 
 // The emit pass (match lists of the candidate records, M:327-336) of up to 8 frames in one launch: blockIdx.y = frame.
@@ -691,7 +701,7 @@ struct ScanBatch {
 };
 
 __global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids,
-                                                          int n_cur_max, int max_rows, ScanBatch bt, u32 *ticket_pool, int quota)
+                                                          int n_cur_max, int max_rows, ScanBatch bt, u32 *ticket_pool, int quota, int n_bounded)
 {
     extern __shared__ u32 lds[];
     const int f = blockIdx.x % bt.n;                       // workgroup-uniform
@@ -702,7 +712,7 @@ __global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restric
     mask.skip_if = bt.skip_if[f];
     const int C = bt.n_cur[f] ? min(*bt.n_cur[f], n_cur_max) : n_cur_max;
     db_count_body<8, 4>(lds, C, db, off, nullptr, nullptr, n_ids, bt.cur[f], max_rows, bt.counts[f], mask, ticket_pool + f * 8 * 32, quota,
-                        ticket_pool, bt.n, (int)(blockIdx.x / bt.n), (int)((gridDim.x + bt.n - 1 - f) / bt.n));
+                        n_bounded, ticket_pool, bt.n, (int)(blockIdx.x / bt.n), (int)((gridDim.x + bt.n - 1 - f) / bt.n));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1035,12 +1045,20 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int resident = ctx->num_cu * 16 / nw;    // 16 waves per CU (128-VGPR kernel)
     int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
     u32 *ticket = nullptr;
-    int quota = 0;
+    int quota = 0, n_bounded = 0;
     if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0 && nj == 8) {
         ticket = ctx->scan_ticket;
         const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 3;
-        quota = (n_ids_max + resident * gens - 1) / (resident * gens);    // records per workgroup
-        grid = (n_ids_max + quota - 1) / quota;                           // grid x quota >= records: every ticket is served
+        // `gens` generations of workgroups: all but the last resident one leave after their share of the database's ROWS, the
+        // last generation draws until the counters are dry (see db_count_body); the row total is the host's when the
+        // context's own database is scanned, else 64 per record
+        const int q_rec = (n_ids_max + resident * gens - 1) / (resident * gens);          // records per workgroup at the average size
+        n_bounded = (n_ids_max + q_rec - 1) / q_rec;                                      // workgroups x q_rec >= records
+        grid = n_bounded + 8 < n_ids_max ? n_bounded + 8 : n_ids_max;                     // + one sweeper per XCD
+        const int64_t rows = db_desc == ctx->db_desc && ctx->db_rows > 0 ? ctx->db_rows : (int64_t)n_ids_max * 64;
+        quota = (int)((rows * q_rec + n_ids_max - 1) / n_ids_max);                        // that many records' worth of ROWS
+        if (quota < 1) quota = 1;
+        if (!ctx->scan_quota_rows) { quota = q_rec; grid = n_bounded; n_bounded = -1; }   // developer switch: the record quota of rounds 2-3a
         if (ctx_alone(ctx) && ctx->scan_gens == 0) { quota = 0; grid = resident; }     // reloc_set_exclusive: one generation, nobody to hand slots to
         if (ctx->scan_gens < 0) { quota = 0; grid = ctx->scan_gens <= -2 ? ctx->num_cu * (-ctx->scan_gens - 1) : resident; }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
     }
@@ -1054,7 +1072,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
 #define RELOC_LAUNCH_SCAN(NJ, EMIT, NW)                                                                                      \
     hipLaunchKernelGGL((k_db_scan<NJ, EMIT, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
-                       m_n, emit_stride, mask, ticket, quota)
+                       m_n, emit_stride, mask, ticket, quota, n_bounded)
     if (m_qidx && ctx->latency_shapes) {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 8); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 8); else RELOC_LAUNCH_SCAN(8, true, 8);
     } else if (m_qidx) {
@@ -1099,10 +1117,18 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     int per_frame = (resident * gens + n - 1) / n;
     if (per_frame > n_ids) per_frame = n_ids;
     if (per_frame < 1) per_frame = 1;
-    const int quota = (n_ids + per_frame - 1) / per_frame;
-    per_frame = (n_ids + quota - 1) / quota;                       // per_frame x quota >= records: every ticket is served
+    // per frame: per_frame workgroups with a row budget (together: the whole database) + one sweeper behind them that draws
+    // until the counters are dry (db_count_body)
+    const int q_rec = (n_ids + per_frame - 1) / per_frame;                           // records per workgroup at the average size
+    const int n_bounded = (n_ids + q_rec - 1) / q_rec;
+    int quota = (int)(((c0->db_rows > 0 ? c0->db_rows : (int64_t)n_ids * 64) * q_rec + n_ids - 1) / n_ids);   // in ROWS
+    if (quota < 1) quota = 1;
+    per_frame = n_bounded + 1;                                                       // + one sweeper per frame
+    if (per_frame > n_ids) per_frame = n_ids;
+    int nb_arg = n_bounded;
+    if (!c0->scan_quota_rows) { quota = q_rec; per_frame = n_bounded; nb_arg = -1; }
     hipLaunchKernelGGL(k_db_scan_batch, dim3(per_frame * n), dim3(256), lds_all, c0->stream, (const uint4 *)c0->db_desc, c0->db_off,
-                       n_ids, c0->max_feat, max_rows, bt, c0->scan_ticket, quota);
+                       n_ids, c0->max_feat, max_rows, bt, c0->scan_ticket, quota, nb_arg);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }

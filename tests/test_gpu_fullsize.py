@@ -39,6 +39,43 @@ def test_db_scan_10k_records(engine, oracle):
             assert cq[r] == len(oracle.match_mutual(desc[off[r]:off[r + 1]], cur[:q])[0]), (q, r)
 
 
+@pytest.mark.parametrize("rows", ["ragged", "fixed64", 7, "spiky"])
+def test_db_scan_scheduling_forms_agree_on_every_record(engine, rows):
+    """the whole-database scan in the generations form (workgroups with a row budget + sweepers: what a context runs beside
+    other streams) and in the one-generation form (reloc_set_exclusive) must write the SAME count for EVERY record -- a ticket
+    that no workgroup served would leave a stale count -- on ragged, uniform, tiny and very uneven record sizes"""
+    rng = np.random.default_rng(31)
+    cur = synth.random_descriptors(rng, 500)
+    L = 6000
+    if rows == "spiky":             # a few huge records among tiny ones: budgets are exhausted by single records
+        n = rng.integers(1, 20, L); n[rng.choice(L, 40, replace=False)] = rng.integers(1500, 4000, 40)
+        off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
+        desc = synth.random_descriptors(rng, int(off[-1])); pts = np.zeros((int(off[-1]), 3), np.float32)
+        poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1))
+    else:
+        desc, pts, off, poses = synth.descriptor_db(rng, L, rows, cur, planted_records=(5, 3000, L - 1))
+    engine.db_upload(desc, pts, off, poses)
+    dcur = engine.to_device(cur)
+    out = {}
+    try:
+        for form in (True, False, True):
+            engine.set_exclusive(form)
+            cnt = engine.dev_alloc(L * 4)
+            engine.h2d(cnt, np.full(L, -7, np.int32))              # poison: an unserved record keeps it
+            engine.db_match_counts_dev(dcur, 500, cnt)
+            got = np.empty(L, np.int32)
+            engine.d2h(got, cnt)
+            engine.dev_free(cnt)
+            out.setdefault(form, []).append(got)
+    finally:
+        engine.set_exclusive(None)
+        engine.dev_free(dcur)
+    assert (out[False][0] >= 0).all(), "a record was never scored"
+    np.testing.assert_array_equal(out[False][0], out[True][0])
+    np.testing.assert_array_equal(out[True][1], out[True][0])
+    assert (out[True][0] <= np.minimum(np.diff(off), 500)).all()
+
+
 def test_hamming_matrix_20k(engine):
     rng = np.random.default_rng(20260505)
     a = synth.random_descriptors(rng, 20000)

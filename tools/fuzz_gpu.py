@@ -16,7 +16,7 @@ O.build()
 e = Engine(0, 1280, 720, 8192)
 rng = np.random.default_rng(args.seed)
 t_end = time.time() + args.seconds
-n_case = {"match": 0, "knn": 0, "db": 0, "db_small": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
+n_case = {"match": 0, "knn": 0, "db": 0, "db_small": 0, "db_big": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
 
 
 def descs(n, dup_p=0.1, low_entropy=False):
@@ -78,6 +78,18 @@ while time.time() < t_end:
             if k: db[off[r]:off[r] + k] = synth.perturb_descriptors(rng, cur[rng.choice(Q, k, replace=False)], 0.05)
         e.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
         if not np.array_equal(e.db_match_counts(cur), O.db_match_counts(db, off, cur)): fail(kind, (L, Q, le))
+    elif kind == "db_big":        # more records than resident workgroups: ticket counters, row budgets, sweepers; both scheduling forms
+        L = int(rng.integers(1100, 3500)); Q = int(rng.integers(65, 400))
+        n = rng.integers(0, 24, L); n[rng.choice(L, 5, replace=False)] = rng.integers(100, 900, 5)
+        off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
+        cur = descs(Q); db = descs(max(int(off[-1]), 1))[: int(off[-1])]
+        e.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
+        x = O.db_match_counts(db, off, cur)
+        for form in (False, True):
+            e.set_exclusive(form)
+            g = e.db_match_counts(cur)
+            e.set_exclusive(None)
+            if not np.array_equal(g, x): fail(kind, (L, Q, form, int((g != x).sum())))
     elif kind == "matrix":
         na, nb = int(rng.integers(1, 300)), int(rng.integers(1, 5000))
         a, b = descs(na), descs(nb)
