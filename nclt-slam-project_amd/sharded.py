@@ -12,9 +12,9 @@ A 10k-record database is 20 MB: it fits one MI355X thousands of times over, so s
 throughput, not capacity (bench.py shards frames instead; this module is the path for databases
 that are scanned faster split, BASELINE.json config 4).
 
-Load order: PyTorch-ROCm ships its own HIP runtime.  `import torch` must happen before the first Engine is created
-(before libreloc_hip.so loads /opt/rocm's runtime), otherwise torch reports "No HIP GPUs are available" when it
-initialises later.  bench.py and tests/conftest.py import torch first; do the same in a process that uses this module.
+Load order: PyTorch-ROCm ships its own HIP runtime, and a process must run on ONE.  `_native.load()` sees to that whatever
+the import order (it maps torch's runtime first when torch is installed but not imported yet):
+nothing has to be imported first.
 """
 from __future__ import annotations
 

@@ -3,8 +3,8 @@ import sys
 
 import pytest
 
-try:        # torch brings its own HIP runtime: it has to be loaded before libreloc_hip.so pulls in /opt/rocm's, or torch later
-    import torch  # noqa: F401  # reports "No HIP GPUs are available" (only the multi-GPU exchange and bench.py use torch)
+try:        # not needed for the load order any more (_native.load() keeps the process on one HIP runtime either way); imported
+    import torch  # noqa: F401  # here so that the 1-2 minutes of a first `import torch` on a fresh box are not billed to a test
 except ImportError:
     pass
 
