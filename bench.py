@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one batch of `--frames-per-step` synthetic 640x480 frames, each taken through the whole
+A step = one batch of `--frames-per-step` synthetic 640x480 frames (32 distinct ones, cycled), each taken through the whole
 hot path ON THE DEVICE: gray -> ORB(500) -> whole-database mutual-match scan (10 000 records x 64
 descriptors, the reference's global relocalisation search, G:329-344) -> top-25 candidates ->
 mutual match lists -> PnP-RANSAC(200) -> gates -> anchor pose; every frame's 96-byte result record is
@@ -444,6 +444,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix", action="store_true")
     ap.add_argument("--no-ingest", action="store_true", help="skip the second timed run with frames uploaded from host memory")
+    ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames cycled through (each with its own planted record)")
     ap.add_argument("--no-2hz", action="store_true", help="skip the tick latency at the reference's 2 Hz cadence (~50 s of mostly idle time)")
     ap.add_argument("--ticks-2hz", type=int, default=40)
     ap.add_argument("--no-extra-scans", action="store_true", help="skip roofline_ragged / roofline_small_q")
@@ -485,7 +486,7 @@ def main():
     S, NB = args.streams, max(1, min(8, args.batch))
     groups = [[Engine(local_rank, W, H, 2048) for _ in range(NB)] for _ in range(S)]
     engines = [e for g in groups for e in g]
-    n_distinct = 8
+    n_distinct = args.distinct_frames
     frames, db, base_poses = build_workload(engines[0], args.records, args.rows, n_distinct)
     engines[0].db_upload(*db)
     for e in engines[1:]:
@@ -726,7 +727,7 @@ def main():
             "config": {"workload": f"{W}x{H} BGR frames, {L}-record landmark DB ({T} descriptors, rows={args.rows}), "
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
                                    f"top-25 PnP-RANSAC(200); frames resident in HBM, every frame's 96-byte result record written to pinned host memory by the tick's last kernel",
-                       "frames_per_step": B, "preroll_steps": PREROLL_STEPS, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
+                       "frames_per_step": B, "distinct_frames": n_distinct, "preroll_steps": PREROLL_STEPS, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
                        "parallelism": "frames sharded across ranks, database replicated, no collective"},
             "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95)), max=float(per_step.max()),
                             first=[round(float(x), 2) for x in per_step[:6]]),
