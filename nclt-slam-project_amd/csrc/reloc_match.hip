@@ -879,8 +879,7 @@ __device__ __forceinline__ u32 rows_min16(u32 (&d)[R], int lane)
 // the queries arrive four at a time, requested together -- round 2 fetched each query through the scalar cache inside the row
 // loop and waited for it, eight dependent round trips per record.
 // Both keys are 16-bit (distance << 6 | query resp. lane, < 2^15): v_lshlrev_b16 / v_or / v_min_u16, all full rate.
-// A wave takes two records per turn and requests the first 64 rows of both before it works on either, so half of its HBM
-// latency runs under its own arithmetic instead of only under that of the SIMD's other waves.
+// One wave owns a record; the SIMD's eight waves hide each other's HBM latency.
 template <int G, bool HOIST>
 __global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_db_scan_rows(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
                                                                 const uint4 *__restrict__ cur, const int32_t *__restrict__ n_cur_p,
@@ -974,18 +973,27 @@ __global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8
         }
         if (lane == 0) counts[r] = total;
     };
-    // Two records per turn: both first chunks are requested before either is worked on, so the second record's HBM latency
-    // runs under the first record's arithmetic.  (A prefetch carried around the loop does not survive the compiler: the
-    // register copy at the back edge is a use, and its s_waitcnt vmcnt(0) sits in front of the next request -- ISA checked.)
-    for (int r = gw; r < n_rec; r += 2 * nw) {
-        int64_t row0_a = 0, row0_b = 0;
-        int n_a = 0, n_b = 0;
-        uint4 a0 = {}, b0 = {}, a1 = {}, b1 = {};
-        const bool two = r + nw < n_rec;
-        fetch0(r, row0_a, n_a, a0, b0);
-        if (two) fetch0(r + nw, row0_b, n_b, a1, b1);
-        process(r, row0_a, n_a, a0, b0);
-        if (two) process(r + nw, row0_b, n_b, a1, b1);
+    // NT records per turn (all first chunks requested before any is worked on).  ONE is the fastest (100 000 x 64 rows, same
+    // box, profiles/r3_small_q_records_per_turn.log: Q = 8: 43.0 / 45.9 / 49.7 us for 1 / 2 / 4 records per turn, Q = 1: 33.9 /
+    // 35.0 / 37.9): with longer turns the SIMD's eight waves fall into step -- all compute, then all wait for their rows --
+    // while short turns keep some of them at each stage.  (A prefetch carried around the loop does not survive the
+    // compiler: the register copy at the back edge is a use, and its s_waitcnt vmcnt(0) sits in front of the next request.)
+#ifndef ROWS_PER_TURN
+#define ROWS_PER_TURN 1
+#endif
+    constexpr int NT = ROWS_PER_TURN;
+    for (int r = gw; r < n_rec; r += NT * nw) {
+        int64_t row0[NT];
+        int n[NT];
+        uint4 a[NT], b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            row0[t] = 0; n[t] = 0; a[t] = uint4{}; b[t] = uint4{};
+            if (r + t * nw < n_rec) fetch0(r + t * nw, row0[t], n[t], a[t], b[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (r + t * nw < n_rec) process(r + t * nw, row0[t], n[t], a[t], b[t]);
     }
 }
 
