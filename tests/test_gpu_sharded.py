@@ -90,7 +90,9 @@ def test_candidate_ranking_with_massive_ties(engine, oracle, k):
     for rows, flip in ((40, 0.02), (40, 0.02), (24, 0.30), (8, 0.5)):      # two strong prototypes, one weak, one below MIN_MATCHES
         src = rng.choice(feat["n"], rows, replace=False)
         protos.append(synth.perturb_descriptors(rng, feat["desc"][src], flip))
-    for L, weights in ((3000, (0.3, 0.3, 0.3, 0.1)), (600, (0.0, 0.005, 0.0, 0.995)), (40, (0.0, 0.0, 0.0, 1.0))):
+    # from 40 records (a thread owns at most one) to 20000 (20 per thread)
+    for L, weights in ((3000, (0.3, 0.3, 0.3, 0.1)), (600, (0.0, 0.005, 0.0, 0.995)), (40, (0.0, 0.0, 0.0, 1.0)),
+                       (16384, (0.45, 0.45, 0.05, 0.05)), (20000, (0.3, 0.3, 0.3, 0.1))):
         which = rng.choice(4, L, p=weights)
         n = np.array([len(protos[w]) for w in which], np.int64)
         off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
@@ -106,7 +108,7 @@ def test_candidate_ranking_with_massive_ties(engine, oracle, k):
         np.testing.assert_array_equal(ids[: len(exp)], exp)
         np.testing.assert_array_equal(cnt[: len(exp)], counts[exp])
         assert (ids[len(exp):] == -1).all() and (cnt[len(exp):] == 0).all()
-        if L == 3000:
+        if L >= 3000:
             assert len(exp) == k and len(set(counts[exp].tolist())) <= 2           # the winners really are a tie group
 
 
