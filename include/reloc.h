@@ -286,7 +286,9 @@ int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, 
 int reloc_tick_accumulate_dev(reloc_ctx *ctx, const uint16_t *depth_mm_dev, int w, int h, const double base_pose[7],
                               int silence_ok);
 int reloc_accumulate_result(reloc_ctx *ctx, int32_t *appended, int32_t *n_kpts, double *nearest_m);
-/* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12). */
+/* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12).  A candidate whose RANSAC consensus set
+ * is smaller than the tick's inlier gate (min_inliers / global_min_inliers) cannot be accepted and is not refined: its record
+ * carries the inlier count, the RANSAC pose and reproj 0. */
 int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches,
                      int32_t *n_inl, int32_t *ok, double *reproj, double *Rt);
 /* Sharded database (one rank per GPU): per-record mutual-match counts are local; the caller

@@ -343,5 +343,5 @@ int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_
 int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride, int channels, int order,
                 int nfeatures);
 int pnp_run_candidates_batch(reloc_ctx *const *ctxs, int n, int n_cand_max, const uint64_t *seeds);
-int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4],
-                       int iters, float thr_px, double conf, uint64_t seed, int min_m);
+int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4], int iters,
+                       float thr_px, double conf, uint64_t seed, int min_m, const int32_t *relocating_dev, int gate_local, int gate_global);

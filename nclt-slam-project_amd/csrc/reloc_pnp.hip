@@ -292,12 +292,17 @@ struct PnpParams {
     int iters;
     int stride;      // rows per candidate in obj/img/inlier arrays
     int min_m;       // fewer correspondences than this => no model (matcher gate M:330, or 4)
+    // the tick's inlier gate (M:349 MIN_INLIERS / G:381 RELOC_MIN_INLIERS), known before the refinement: a candidate whose
+    // consensus set is smaller cannot be accepted whatever its refined pose, so k_pnp_finish does not refine it.  0: no gate
+    // (cv2.solvePnPRansac through the shim refines everything).
+    int gate_local, gate_global;
 };
 
 // Frame-batched launches (reloc_tick_batch_dev, the sharded halves): the candidates of up to 8 contexts in one launch per
 // kernel; the frame is the last grid dimension.
 struct PnpFrame {
     const float *obj, *img; const int32_t *m_arr, *n_cand_p; double *Rt; int32_t *cnt, *inl; PnpOut *out; uint64_t seed;
+    const int32_t *relocating;
 };
 struct PnpBatch { PnpFrame f[RELOC_BATCH_MAX]; };
 
@@ -625,7 +630,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
                                                 const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                 const PnpParams &prm, const double *__restrict__ Rt_all,
                                                 const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
-                                                PnpOut *__restrict__ out)
+                                                PnpOut *__restrict__ out, const int32_t *__restrict__ relocating_p)
 {
     const int c = blockIdx.x;
     if (n_cand_p && c >= *n_cand_p) return;
@@ -647,7 +652,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
         cl[j] = -1;
         if (j < nj && h < prm.iters) cl[j] = cnt[(size_t)c * MAX_HYP + h];
     }
-    int s_best_v = -1;
+    int s_best_v = -1, s_best_count = 0;
     if (m >= prm.min_m) {
         int niters = prm.iters, best_count = RELOC_PNP_SAMPLE - 1, pos = 0;
         const double log_num = ransac_log_num(prm.conf);
@@ -670,6 +675,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
                 if (j == fj) ch = __builtin_amdgcn_readlane(cl[j], fl);    // wave-uniform branch
             }
             s_best_v = found;
+            s_best_count = ch;
             best_count = ch;
             niters = ransac_update_iters(log_num, (double)(m - ch) / (double)m, niters);
             pos = found + 1;
@@ -683,6 +689,26 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
     }
     double Rt[12];
     for (int k = 0; k < 12; ++k) Rt[k] = Rt_all[((size_t)c * MAX_HYP + best) * 12 + k];
+    {
+        // The tick's inlier gate is known here: a consensus set below it is rejected by the finalisation whatever the refined
+        // pose (M:349, G:381) -- and most candidates of a whole-database search are wrong records with a handful of chance
+        // inliers, on which Levenberg-Marquardt takes its longest (ill-conditioned, many rejected steps).  They keep the
+        // RANSAC pose and skip the inlier list, the refinement and the error: the kernel lasts as long as its slowest wave,
+        // which is now a candidate that can win (k_pnp_finish 24.5 -> see DESIGN.md us in the benchmark's tick).
+        const int gate = relocating_p ? (*relocating_p ? prm.gate_global : prm.gate_local) : 0;
+        if (s_best_count < gate) {
+            if (lane == 0) {
+                for (int k = 0; k < 12; ++k) po.Rt[k] = Rt[k];
+                po.rvec[0] = po.rvec[1] = po.rvec[2] = 0.0;
+                po.reproj_mean = 0.0;
+                po.ok = 1;
+                po.n_inl = s_best_count;
+                po.best_h = best;
+                po.n_matches = m;
+            }
+            return;
+        }
+    }
     // inlier list (ascending) by ballot compaction
     int n = 0;
     for (int i0 = 0; i0 < m; i0 += 64) {
@@ -765,10 +791,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
                                                    const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
                                                    PnpParams prm, const double *__restrict__ Rt_all,
                                                    const int32_t *__restrict__ cnt, int32_t *__restrict__ inl_out,
-                                                   PnpOut *__restrict__ out)
+                                                   PnpOut *__restrict__ out, const int32_t *__restrict__ relocating_p)
 {
     RELOC_SMALL_KERNEL_PRIO();
-    pnp_finish_body(obj, img, m_arr, n_cand_p, prm, Rt_all, cnt, inl_out, out);
+    pnp_finish_body(obj, img, m_arr, n_cand_p, prm, Rt_all, cnt, inl_out, out, relocating_p);
 }
 // grid (n_cand_max, frames)
 template <int WAVES>
@@ -777,7 +803,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) 
     RELOC_SMALL_KERNEL_PRIO();
     const PnpFrame &F = b.f[blockIdx.y];
     prm.seed = F.seed;
-    pnp_finish_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt, F.inl, F.out);
+    pnp_finish_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt, F.inl, F.out, F.relocating);
 }
 
 
@@ -792,18 +818,20 @@ static PnpParams make_params(const double K4[4], int iters, float thr_px, double
     p.iters = iters;
     p.stride = stride;
     p.min_m = min_m < RELOC_PNP_SAMPLE ? RELOC_PNP_SAMPLE : min_m;
+    p.gate_local = p.gate_global = 0;
     return p;
 }
 
 int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev, const double K4[4], int iters,
-                       float thr_px, double conf, uint64_t seed, int min_m)
+                       float thr_px, double conf, uint64_t seed, int min_m, const int32_t *relocating_dev, int gate_local, int gate_global)
 {
     if (n_cand_max <= 0) return RELOC_OK;
     if (n_cand_max > MAX_CAND || iters < 1 || iters > MAX_HYP) {
         reloc_set_error("pnp: n_cand %d (max %d) iters %d (max %d)", n_cand_max, MAX_CAND, iters, MAX_HYP);
         return RELOC_E_CAPACITY;
     }
-    const PnpParams prm = make_params(K4, iters, thr_px, conf, seed, MAX_REC_ROWS, min_m);
+    PnpParams prm = make_params(K4, iters, thr_px, conf, seed, MAX_REC_ROWS, min_m);
+    prm.gate_local = gate_local; prm.gate_global = gate_global;
     reloc_prof_begin(ctx, RELOC_PROF_PNP);
     hipLaunchKernelGGL(k_pnp_hyp, dim3((iters + 63) / 64, n_cand_max), dim3(HYP_BLOCK), 0, ctx->stream, ctx->p_obj, ctx->p_img,
                        ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt);
@@ -811,10 +839,10 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
                        n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, (uint8_t *)nullptr, MAX_HYP);
     if (ctx->latency_shapes)
         hipLaunchKernelGGL(k_pnp_finish<1>, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
-                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
+                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out, relocating_dev);
     else
         hipLaunchKernelGGL(k_pnp_finish<4>, dim3(n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
-                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out);
+                           n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, ctx->p_inl, ctx->p_out, relocating_dev);
     reloc_prof_end(ctx, RELOC_PROF_PNP);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
@@ -829,14 +857,15 @@ int pnp_run_candidates_batch(reloc_ctx *const *ctxs, int n, int n_cand_max, cons
         reloc_set_error("pnp batch: n %d n_cand %d (max %d) iters %d (max %d)", n, n_cand_max, MAX_CAND, iters, MAX_HYP);
         return RELOC_E_CAPACITY;
     }
-    const PnpParams prm = make_params(c0->K4, iters, (float)c0->prm.ransac_reproj_px, c0->prm.ransac_confidence, 0, MAX_REC_ROWS,
-                                      c0->prm.min_matches);
+    PnpParams prm = make_params(c0->K4, iters, (float)c0->prm.ransac_reproj_px, c0->prm.ransac_confidence, 0, MAX_REC_ROWS,
+                                c0->prm.min_matches);
+    prm.gate_local = c0->prm.min_inliers; prm.gate_global = c0->prm.global_min_inliers;
     PnpBatch b;
     for (int f = 0; f < RELOC_BATCH_MAX; ++f) {
         reloc_ctx *c = ctxs[f < n ? f : 0];
         PnpFrame &F = b.f[f];
         F.obj = c->p_obj; F.img = c->p_img; F.m_arr = c->m_n; F.n_cand_p = c->cand_n; F.Rt = c->p_Rt; F.cnt = c->p_cnt; F.inl = c->p_inl;
-        F.out = c->p_out; F.seed = seeds ? seeds[f < n ? f : 0] : 0;
+        F.out = c->p_out; F.seed = seeds ? seeds[f < n ? f : 0] : 0; F.relocating = c->tick_flags;
     }
     reloc_prof_begin(c0, RELOC_PROF_PNP);
     hipLaunchKernelGGL(k_pnp_hyp_batch, dim3((iters + 63) / 64, n_cand_max, n), dim3(HYP_BLOCK), 0, c0->stream, b, prm);
@@ -898,7 +927,7 @@ RELOC_API int reloc_pnp_ransac(reloc_ctx *ctx, const float *obj, const float *im
     // the single-call path has no MIN_MATCHES gate (that gate belongs to the matcher, M:330)
     int rc;
     ctx->latency_shapes = true;
-    rc = pnp_run_candidates(ctx, 1, nullptr, K4, iters, thr_px, conf, seed, RELOC_PNP_SAMPLE);
+    rc = pnp_run_candidates(ctx, 1, nullptr, K4, iters, thr_px, conf, seed, RELOC_PNP_SAMPLE, nullptr, 0, 0);
     ctx->latency_shapes = false;
     if (rc) return rc;
     PnpOut po;

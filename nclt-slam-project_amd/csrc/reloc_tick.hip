@@ -633,7 +633,8 @@ static int tick_solve(reloc_ctx *ctx, const TickParams &prm, uint64_t seed)
                         ctx->m_dist, ctx->m_n, MAX_REC_ROWS, &emit);
     if (!rc)
         rc = pnp_run_candidates(ctx, MAX_CAND, ctx->cand_n, ctx->K4, ctx->prm.ransac_iterations, (float)ctx->prm.ransac_reproj_px,
-                                ctx->prm.ransac_confidence, seed, ctx->prm.min_matches);
+                                ctx->prm.ransac_confidence, seed, ctx->prm.min_matches, ctx->tick_flags, ctx->prm.min_inliers,
+                                ctx->prm.global_min_inliers);
     ctx->latency_shapes = false;
     if (rc) return rc;
     TickParams fin = prm;
