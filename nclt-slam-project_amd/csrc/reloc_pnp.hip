@@ -312,9 +312,16 @@ struct PnpBatch { PnpFrame f[RELOC_BATCH_MAX]; };
 // the smallest error (lowest root on ties: the specification's first-minimum rule).  Rounds 1-2 walked the roots one after
 // the other in one lane: 4 us of an 18 us dependent chain.
 constexpr int HYP_BLOCK = 256;
+// the tick's inlier gate (0 outside a tick), see PnpParams
+__device__ __forceinline__ int pnp_gate(const PnpParams &prm, const int32_t *relocating_p)
+{
+    return relocating_p ? (*relocating_p ? prm.gate_global : prm.gate_local) : 0;
+}
+
 __device__ __forceinline__ void pnp_hyp_body(const float *__restrict__ obj, const float *__restrict__ img,
                                              const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
-                                             const PnpParams &prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
+                                             const PnpParams &prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt,
+                                             const int32_t *__restrict__ relocating_p)
 {
     const int c = blockIdx.y;
     if (n_cand_p && c >= *n_cand_p) return;
@@ -327,7 +334,8 @@ __device__ __forceinline__ void pnp_hyp_body(const float *__restrict__ obj, cons
     int32_t *cn = cnt + (size_t)c * MAX_HYP + h;
     int idx[4];
     PNP_T(0);
-    if (m < prm.min_m || !pnp_sample(prm.seed, h, m, idx)) { if (sol == 0) *cn = -1; return; }
+    // fewer correspondences than the inlier gate: no consensus set of this candidate can be accepted -- no hypotheses at all
+    if (m < prm.min_m || m < pnp_gate(prm, relocating_p) || !pnp_sample(prm.seed, h, m, idx)) { if (sol == 0) *cn = -1; return; }
     PNP_T(1);
     double P[9], xn[6], Rt[12];
     for (int k = 0; k < 3; ++k) {
@@ -364,10 +372,11 @@ __device__ __forceinline__ void pnp_hyp_body(const float *__restrict__ obj, cons
 }
 __global__ __launch_bounds__(HYP_BLOCK) void k_pnp_hyp(const float *__restrict__ obj, const float *__restrict__ img,
                                                 const int32_t *__restrict__ m_arr, const int32_t *__restrict__ n_cand_p,
-                                                PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt)
+                                                PnpParams prm, double *__restrict__ Rt_out, int32_t *__restrict__ cnt,
+                                                const int32_t *__restrict__ relocating_p)
 {
     RELOC_SMALL_KERNEL_PRIO();
-    pnp_hyp_body(obj, img, m_arr, n_cand_p, prm, Rt_out, cnt);
+    pnp_hyp_body(obj, img, m_arr, n_cand_p, prm, Rt_out, cnt, relocating_p);
 }
 // grid (ceil(iters/64), n_cand_max, frames)
 __global__ __launch_bounds__(HYP_BLOCK) void k_pnp_hyp_batch(PnpBatch b, PnpParams prm)
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(HYP_BLOCK) void k_pnp_hyp_batch(PnpBatch b, PnpPara
     RELOC_SMALL_KERNEL_PRIO();
     const PnpFrame &F = b.f[blockIdx.z];
     prm.seed = F.seed;
-    pnp_hyp_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt);
+    pnp_hyp_body(F.obj, F.img, F.m_arr, F.n_cand_p, prm, F.Rt, F.cnt, F.relocating);
 }
 
 
@@ -695,7 +704,7 @@ __device__ __forceinline__ void pnp_finish_body(const float *__restrict__ obj, c
         // inliers, on which Levenberg-Marquardt takes its longest (ill-conditioned, many rejected steps).  They keep the
         // RANSAC pose and skip the inlier list, the refinement and the error: the kernel lasts as long as its slowest wave,
         // which is now a candidate that can win (k_pnp_finish 24.5 -> see DESIGN.md us in the benchmark's tick).
-        const int gate = relocating_p ? (*relocating_p ? prm.gate_global : prm.gate_local) : 0;
+        const int gate = pnp_gate(prm, relocating_p);
         if (s_best_count < gate) {
             if (lane == 0) {
                 for (int k = 0; k < 12; ++k) po.Rt[k] = Rt[k];
@@ -834,7 +843,7 @@ int pnp_run_candidates(reloc_ctx *ctx, int n_cand_max, const int32_t *n_cand_dev
     prm.gate_local = gate_local; prm.gate_global = gate_global;
     reloc_prof_begin(ctx, RELOC_PROF_PNP);
     hipLaunchKernelGGL(k_pnp_hyp, dim3((iters + 63) / 64, n_cand_max), dim3(HYP_BLOCK), 0, ctx->stream, ctx->p_obj, ctx->p_img,
-                       ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt);
+                       ctx->m_n, n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, relocating_dev);
     hipLaunchKernelGGL(k_pnp_score, dim3(iters, n_cand_max), dim3(64), 0, ctx->stream, ctx->p_obj, ctx->p_img, ctx->m_n,
                        n_cand_dev, prm, ctx->p_Rt, ctx->p_cnt, (uint8_t *)nullptr, MAX_HYP);
     if (ctx->latency_shapes)
