@@ -286,7 +286,11 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
     if device_path:
         # exchange resident in HBM: top-k lists, merge, candidate hand-over and result records never visit the host inside a
         # batch; DEPTH batches in flight, each on its own stream
-        sr = DeviceShardedRelocalizer(shard, rank, world, torch.device("cuda", local_rank), batch=BATCH, depth=DEPTH)
+        forced = bool(args.force_dist and dist is not None)
+        if forced and args.backend != "nccl":
+            raise SystemExit("bench.py: --force-dist routes device tensors through the collective: it needs --backend nccl")
+        sr = DeviceShardedRelocalizer(shard, rank, world, torch.device("cuda", local_rank), batch=BATCH, depth=DEPTH,
+                                      force_collective=forced)
 
         flight = []                                                       # batches in flight, ACROSS steps: a step that drained its
                                                                           # own batches would empty the device once per step (round 3,
@@ -354,7 +358,10 @@ def bench_sharded(args, rank, world, local_rank, dist, torch):
             "config": {"workload": f"{W}x{H} frames, {L}-record DB split over {world} rank(s), batches of {BATCH} frames ({DEPTH} in flight): "
                                    f"ORB on every rank, ONE shard-scan launch per batch, one all-gather of the {BATCH} top-25 lists, PnP on "
                                    f"the owners, one all-gather of the {BATCH} results",
-                       "frames_per_step": B, "records": L, "shard_records": shard.n_records},
+                       "frames_per_step": B, "records": L, "shard_records": shard.n_records,
+                       "collective": ("none (single rank: the exchange is a device-to-device copy)" if dist is None else
+                                      f"torch.distributed {args.backend} all_gather_into_tensor x 2 per batch, world {world}"
+                                      + (" (forced at world 1)" if args.force_dist and world == 1 else ""))},
             "last_outcome": int(last["outcome"]), "last_inliers": int(last["n_inliers"])}))
 
 
@@ -425,7 +432,56 @@ def _cpu_model():
     return "unknown"
 
 
-def main():
+def launch_plan(args, argv, env):
+    """What `python bench.py --gpus N` has to do before anything touches the GPU (BASELINE.json north_star: frames/s at 1, 2, 4
+    and 8 GPUs; the driver's N > 1 line is `python -m torch.distributed.run ... bench.py --gpus N`, a bare `python bench.py
+    --gpus N` must measure N GPUs as well, not one):
+        ("run",)          this process is a rank (WORLD_SIZE == --gpus) or the single-GPU run
+        ("spawn", cmd)    --gpus N > 1 outside a launcher: start N ranks as a FRESH child process (never an exec: this
+                          interpreter may already hold a GPU context in other callers), relay its output, exit with its code
+        ("error", text)   WORLD_SIZE and --gpus disagree: refuse instead of printing a line for the wrong GPU count"""
+    world = env.get("WORLD_SIZE")
+    if world is None:
+        if args.gpus <= 1:
+            return ("run",)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        return ("spawn", cmd)
+    try:
+        w = int(world)
+    except ValueError:
+        return ("error", f"WORLD_SIZE={world!r} is not a number")
+    if w != args.gpus:
+        return ("error", f"--gpus {args.gpus} but the launcher started WORLD_SIZE={w} rank(s): the line would carry the wrong "
+                         f"GPU count; launch with --nproc-per-node {args.gpus} or pass --gpus {w}")
+    return ("run",)
+
+
+def init_dist(args, torch, rank, world, local_rank):
+    """torch.distributed group of the run, or None.  backend "nccl" IS RCCL on ROCm.  --force-dist initialises the group at
+    world size 1 too (one rank, one GPU), so that communicator creation, barrier, all_reduce and all_gather_into_tensor run over
+    RCCL beside this library's HIP runtime on a one-GPU box."""
+    if world == 1 and not args.force_dist:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    return dist
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -451,7 +507,18 @@ def main():
     ap.add_argument("--matrix-only", action="store_true",
                     help="BASELINE config 5 shape: the 20000 x 20000 u16 Hamming matrix, row blocks split over the ranks, no\n"
                          "reduction (not the judged default; reports its own JSON line)")
-    args = ap.parse_args()
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the torch.distributed group at world size 1 too and route barrier / all_reduce / both\n"
+                         "all-gathers of --shard-db through it (RCCL with --backend nccl) instead of the single-rank shortcut")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+    plan = launch_plan(args, argv, os.environ)
+    if plan[0] == "error":
+        raise SystemExit("bench.py: " + plan[1])
+    if plan[0] == "spawn":
+        import subprocess
+        r = subprocess.run(plan[1], cwd=ROOT)          # the ranks print on this process's stdout / stderr
+        raise SystemExit(r.returncode)
     global W, H
     if args.size == "720p":
         W, H = 1280, 720
@@ -465,14 +532,7 @@ def main():
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    dist = init_dist(args, torch, rank, world, local_rank)
 
     from nclt_slam_project_amd.engine import Engine
 
@@ -728,7 +788,8 @@ def main():
                                    f"global relocalization tick per frame: ORB(500) + whole-DB mutual Hamming scan + "
                                    f"top-25 PnP-RANSAC(200); frames resident in HBM, every frame's 96-byte result record written to pinned host memory by the tick's last kernel",
                        "frames_per_step": B, "distinct_frames": n_distinct, "preroll_steps": PREROLL_STEPS, "streams": args.streams, "frames_per_scan_launch": NB, "records": L, "descriptors": T,
-                       "parallelism": "frames sharded across ranks, database replicated, no collective"},
+                       "parallelism": "frames sharded across ranks, database replicated, no collective",
+                       "process_group": None if dist is None else f"{args.backend}, world {world}: barrier + all_reduce(MAX) of the elapsed time"},
             "step_ms": dict(median=float(np.median(per_step)), p95=float(np.percentile(per_step, 95)), max=float(per_step.max()),
                             first=[round(float(x), 2) for x in per_step[:6]]),
             "host_ingest": ingest, "latency": lat,

@@ -272,10 +272,14 @@ class DeviceShardedRelocalizer:
     it when the ranks are threads of one process (tests)."""
 
     def __init__(self, shard: "HipShard", rank: int, world: int, device, group=None, k: int = K_GLOBAL, bases=None,
-                 batch: int | None = None, depth: int = 2, n_streams: int = 4):
+                 batch: int | None = None, depth: int = 2, n_streams: int = 4, force_collective: bool = False):
+        """force_collective: route both exchanges through the collective at world size 1 too (an initialised process group of
+        one rank, or an injected group) instead of the single-rank device copy -- the way to run the RCCL transport on a
+        one-GPU box (tests, bench.py --shard-db --force-dist)."""
         import torch
         from .engine import Engine
         self.torch, self.shard, self.rank, self.world, self.device, self.group, self.k = torch, shard, rank, world, device, group, k
+        self.collective = world > 1 or bool(force_collective)
         B = batch if batch is not None else max(1, min(8, len(shard.engines)))
         self.B, self.depth = B, depth
         e0 = shard.engine
@@ -311,13 +315,16 @@ class DeviceShardedRelocalizer:
                 cand_local=torch.empty((B, k), dtype=torch.int32, device=device),
                 n_feat=pack[n_res + n_win:].view(torch.int32),
                 all_res=all_res, pack=pack, h_pack=h_pack,
+                # the rank's own result records when a collective moves them (its send buffer, made once: no allocation on the
+                # group's stream per batch); without a collective they are written straight into all_res[rank]
+                send_res=torch.zeros((B, 96), dtype=torch.uint8, device=device) if self.collective else None,
                 h_res=h_pack[:n_res].view(world, B, 96),
                 h_win=h_pack[n_res:n_res + n_win].view(torch.int32).view(B, k),
                 h_nfeat=h_pack[n_res + n_win:].view(torch.int32),
                 event=torch.cuda.Event(), pending=None))
         self._next = 0
         if bases is None:
-            if world == 1:
+            if not self.collective:
                 bases = [shard.base]
             else:
                 t = torch.tensor([shard.base], dtype=torch.int64, device=device)
@@ -328,7 +335,7 @@ class DeviceShardedRelocalizer:
 
     def _all_gather(self, out, inp, stream):
         """out (world, ...) <- inp of every rank, ordered on `stream`"""
-        if self.world == 1:
+        if not self.collective:
             out[0].copy_(inp)
         elif hasattr(self.group, "all_gather_tensor"):
             self.group.all_gather_tensor(self.rank, out, inp, stream)
@@ -355,7 +362,7 @@ class DeviceShardedRelocalizer:
                 Engine.shard_scan_batch_dev(g["engines"][:n], frames_dev, sh.w, sh.h, base_poses, k, sh.base, g["scan"].data_ptr())
             else:                                                 # more ranks than records: this rank only takes part in the exchange
                 g["scan"][:, :k] = -1; g["scan"][:, k:2 * k] = 0; g["scan"][:, 2 * k] = -1
-            if self.world > 1:
+            if self.collective:
                 self._all_gather(g["all_scan"], g["scan"], g["stream"])
                 all_scan, stride = g["all_scan"], self.B * row
             else:
@@ -364,17 +371,16 @@ class DeviceShardedRelocalizer:
             if eng is not None:
                 eng.shard_merge_dev(all_scan.data_ptr(), self.world, stride, n, k, sh.base, sh.n_records, g["win_gid"].data_ptr(),
                                     g["cand_local"].data_ptr(), g["n_feat"].data_ptr())
-                res = g["all_res"][self.rank]
+                res = g["send_res"] if self.collective else g["all_res"][self.rank]
                 Engine.shard_solve_batch_dev(g["engines"][:n], g["cand_local"].data_ptr(), k, base_poses, seeds, res.data_ptr())
             else:
                 wg, _, nf = merge_topk_tensor(all_scan.view(self.world, self.B, row)[:, :n], k, sh.base, 0)
                 g["win_gid"][:n] = wg; g["n_feat"][:n] = nf
-                res = g["all_res"][self.rank]
+                res = g["send_res"] if self.collective else g["all_res"][self.rank]
                 res.zero_()
                 res.view(torch.int32)[:, 18] = 2                  # outcome no_candidates, never picked
-            if self.world > 1:
-                # in place: every rank's own records already sit in its slice of all_res
-                self._all_gather(g["all_res"], g["all_res"][self.rank].clone(), g["stream"])
+            if self.collective:
+                self._all_gather(g["all_res"], g["send_res"], g["stream"])
             g["h_pack"].copy_(g["pack"], non_blocking=True)                      # the one trip to the host, not waited for here
             g["event"].record(g["stream"])
         b = _Batch(g, n)

@@ -223,6 +223,20 @@ def test_config4_device_resident_exchange(engine, config4):
     shard.close()
 
 
+@pytest.mark.parametrize("order", ["torch_first", "library_first"])
+def test_config4_through_rccl_at_world_size_1(order):
+    """the RCCL transport itself, on the one GPU a box has.  A fresh process creates a world-size-1 process
+    group on the nccl backend beside this library's HIP runtime (both creation orders) and takes the config-4 batch (8 frames,
+    100 000 records) through DeviceShardedRelocalizer with BOTH exchanges going through dist.all_gather_into_tensor on the
+    groups' side streams == the unsharded tick (tests/_rccl_world1.py)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_rccl_world1.py"), "100000", order], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-world1 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_batched_tick_one_scan_launch_for_several_frames(engine, config4):
     """reloc_tick_batch_dev: 8 contexts on ONE stream sharing the 100k-record database, ORB per frame, one scan launch
     for the 8 frames (workgroup b scans frame b % 8 with its own ticket counters), ranking / PnP per frame == the
