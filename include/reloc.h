@@ -74,7 +74,7 @@ typedef struct reloc_params {
     double accum_min_dist_m;         /* ACCUM_MIN_DIST_M                      M:87    5.0   */
     double accum_depth_min_m;        /* d_c > 0.5                             M:461   0.5   */
     double accum_depth_max_m;        /* d_c < 15.0                            M:461   15.0  */
-    int32_t gray_coeff_bits;         /* BGR2GRAY fixed point: 14 or 15 (reloc_spec.h) M:305  14    */
+    int32_t gray_coeff_bits;         /* BGR2GRAY fixed point: 15 or 14 (reloc_spec.h) M:305  15    */
     int32_t reserved0;               /* must be 0                                                  */
 } reloc_params;
 

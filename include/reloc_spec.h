@@ -28,9 +28,11 @@
 #define RELOC_ORB_STAGE1_CAP     4096
 
 /* BGR->gray 8-bit fixed point.  Two published OpenCV conventions, chosen by reloc_params.gray_coeff_bits:
- *   14 (default; OpenCV <= 3.x, `yuv_shift`): Y = (B*1868 + G*9617 + R*4899 + 8192)  >> 14
- *   15 (OpenCV 4.x 8-bit path, `gray_shift`):                Y = (B*3735 + G*19235 + R*9798 + 16384) >> 15
- * They differ by +-1 on some pixels.  Neither can be checked against OpenCV offline (parity unpinned). */
+ *   15 (DEFAULT since round 4; OpenCV 4.x 8-bit path, `gray_shift`): Y = (B*3735 + G*19235 + R*9798 + 16384) >> 15
+ *   14 (OpenCV <= 3.x, `yuv_shift`):                  Y = (B*1868 + G*9617 + R*4899 + 8192)  >> 14
+ * The reference can only run on OpenCV >= 4.8 (datasets/nclt/requirements.txt:3; ROS 2 Jazzy / NumPy-2-era wheel: >= 4.10), so the
+ * call it makes at M:305 / R:240 computes the 15-bit form.  The two differ by +-1 on some pixels.  Neither can be checked against
+ * OpenCV offline (parity unpinned). */
 #define RELOC_GRAY_CB            1868
 #define RELOC_GRAY_CG            9617
 #define RELOC_GRAY_CR            4899
@@ -39,6 +41,7 @@
 #define RELOC_GRAY15_CG          19235
 #define RELOC_GRAY15_CR          9798
 #define RELOC_GRAY15_SHIFT       15
+#define RELOC_GRAY_DEFAULT_BITS  RELOC_GRAY15_SHIFT
 /* order argument of the gray stage: bit 0 = channel order (RELOC_ORDER_RGB), bit 1 = the 15-bit coefficient set */
 #define RELOC_GRAY_FLAG_15BIT    2
 

@@ -142,7 +142,7 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_min_dist_m = RELOC_ACCUM_MIN_DIST_M;
     c->prm.accum_depth_min_m = RELOC_ACCUM_DEPTH_MIN_M;
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
-    c->prm.gray_coeff_bits = RELOC_GRAY_SHIFT;
+    c->prm.gray_coeff_bits = RELOC_GRAY_DEFAULT_BITS;     // OpenCV 4.x set (reloc_spec.h)
     c->prm.reserved0 = 0;
     if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
     if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);

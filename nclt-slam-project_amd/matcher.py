@@ -42,7 +42,8 @@ class MatcherConfig:
     min_inliers: int = 10
     consistency_m: float = 5.0
     nfeatures: int = 500
-    gray_coeff_bits: int = 14      # cvtColor fixed point: 14 = SURVEY.md A.1, 15 = OpenCV 4.x (include/reloc_spec.h); fused path only --
+    gray_coeff_bits: int = 15      # cvtColor fixed point: 15 = OpenCV 4.x (what M:305 computes on OpenCV >= 4.8), 14 = OpenCV <= 3.x / SURVEY.md A.1
+                                   # (include/reloc_spec.h); fused path only --
                                    # the cv2-shaped path takes it from its backend (Engine.set_params)
     # global relocalisation (variant G)
     global_reloc: bool = False

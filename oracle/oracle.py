@@ -84,7 +84,10 @@ def _u8(a):
 
 
 # ---------------------------------------------------------------- ORB front end
-def gray_u8(img, order_rgb=False, coeff_bits=14):
+GRAY_DEFAULT_BITS = 15      # RELOC_GRAY_DEFAULT_BITS (include/reloc_spec.h): OpenCV 4.x's 8-bit coefficient set
+
+
+def gray_u8(img, order_rgb=False, coeff_bits=GRAY_DEFAULT_BITS):
     img = _u8(img)
     h, w, _ = img.shape
     out = np.empty((h, w), np.uint8)

@@ -35,7 +35,7 @@
 #define ORC_API __attribute__((visibility("default")))
 
 /* ---- a2: cv2.cvtColor(.., COLOR_BGR2GRAY) (visual_landmark_matcher.py:305) ------------- */
-/* coeff_bits: 14 = SURVEY.md A.1 (the default of reloc_params.gray_coeff_bits), 15 = OpenCV 4.x's gray_shift set */
+/* coeff_bits: 15 = OpenCV 4.x's gray_shift set (RELOC_GRAY_DEFAULT_BITS, the default of reloc_params.gray_coeff_bits), 14 = SURVEY.md A.1 */
 ORC_API int orc_gray_u8_bits(const uint8_t *img, int w, int h, int stride, int order_rgb,
                              uint8_t *gray, int gstride, int coeff_bits)
 {
@@ -59,7 +59,7 @@ ORC_API int orc_gray_u8_bits(const uint8_t *img, int w, int h, int stride, int o
 ORC_API int orc_gray_u8(const uint8_t *img, int w, int h, int stride, int order_rgb,
                         uint8_t *gray, int gstride)
 {
-    return orc_gray_u8_bits(img, w, h, stride, order_rgb, gray, gstride, RELOC_GRAY_SHIFT);
+    return orc_gray_u8_bits(img, w, h, stride, order_rgb, gray, gstride, RELOC_GRAY_DEFAULT_BITS);
 }
 
 /* ---- a4: pyramid geometry and per-level feature quotas ---------------- */

@@ -10,7 +10,7 @@ from oracle import oracle as O
 
 class OracleBackend:
     max_feat = 8192
-    gray_coeff_bits = 14           # the oracle-side twin of reloc_params.gray_coeff_bits
+    gray_coeff_bits = 15           # the oracle-side twin of reloc_params.gray_coeff_bits
 
     def gray(self, img, order_rgb=False):
         return O.gray_u8(img, order_rgb, self.gray_coeff_bits)

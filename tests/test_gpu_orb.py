@@ -22,7 +22,7 @@ def test_gray(engine, oracle, order_rgb):
     # known answer: pure channels
     px = np.zeros((1, 4, 3), np.uint8); px[0, 0] = (255, 0, 0); px[0, 1] = (0, 255, 0); px[0, 2] = (0, 0, 255); px[0, 3] = 255
     g = oracle.gray_u8(np.repeat(px, 64, 0).repeat(16, 1))
-    assert list(g[0, ::16]) == [(255 * 1868 + 8192) >> 14, (255 * 9617 + 8192) >> 14, (255 * 4899 + 8192) >> 14, 255]
+    assert list(g[0, ::16]) == [(255 * 3735 + 16384) >> 15, (255 * 19235 + 16384) >> 15, (255 * 9798 + 16384) >> 15, 255]    # default: OpenCV 4.x set
 
 
 @pytest.mark.parametrize("bits", [14, 15])
@@ -51,7 +51,7 @@ def test_gray_coefficient_sets(engine, oracle, bits):
             np.testing.assert_array_equal(got["desc"], ref["desc"])
             np.testing.assert_array_equal(got["xy"].view(np.uint32), ref["xy"].view(np.uint32))
     finally:
-        engine.set_params(gray_coeff_bits=14)
+        engine.set_params(gray_coeff_bits=15)
     if bits == 15:
         assert (oracle.gray_u8(img, coeff_bits=15) != oracle.gray_u8(img, coeff_bits=14)).any()
 

@@ -18,12 +18,13 @@ def test_gray_formula(oracle):
     img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
     b, g, r = (img[..., k].astype(np.int64) for k in range(3))
     exp = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
-    np.testing.assert_array_equal(oracle.gray_u8(img), exp)
-    np.testing.assert_array_equal(oracle.gray_u8(img[..., ::-1].copy(), order_rgb=True), exp)
+    np.testing.assert_array_equal(oracle.gray_u8(img, coeff_bits=14), exp)
+    np.testing.assert_array_equal(oracle.gray_u8(img[..., ::-1].copy(), order_rgb=True, coeff_bits=14), exp)
 
 
 def test_gray_formula_15_bit_set(oracle):
-    """reloc_params.gray_coeff_bits = 15: OpenCV 4.x's published 8-bit coefficients; within 1 grey level of the 14-bit set"""
+    """reloc_params.gray_coeff_bits = 15 (the default since round 4): OpenCV 4.x's published 8-bit coefficients; within 1 grey level
+    of the 14-bit set"""
     rng = np.random.default_rng(10)
     img = rng.integers(0, 256, (41, 67, 3), dtype=np.uint8)
     b, g, r = (img[..., k].astype(np.int64) for k in range(3))
@@ -31,11 +32,12 @@ def test_gray_formula_15_bit_set(oracle):
     got = oracle.gray_u8(img, coeff_bits=15)
     np.testing.assert_array_equal(got, exp)
     np.testing.assert_array_equal(oracle.gray_u8(img[..., ::-1].copy(), order_rgb=True, coeff_bits=15), exp)
-    d = got.astype(int) - oracle.gray_u8(img).astype(int)
+    np.testing.assert_array_equal(oracle.gray_u8(img), exp)                # the default IS the OpenCV 4.x set
+    d = got.astype(int) - oracle.gray_u8(img, coeff_bits=14).astype(int)
     assert np.abs(d).max() <= 1 and (d != 0).any()                        # the two conventions really differ, by one level
     assert 3735 + 19235 + 9798 == 1 << 15 and 1868 + 9617 + 4899 == 1 << 14   # both sets are normalised: white stays 255
     full = np.full((2, 2, 3), 255, np.uint8)
-    assert (oracle.gray_u8(full, coeff_bits=15) == 255).all() and (oracle.gray_u8(full) == 255).all()
+    assert (oracle.gray_u8(full, coeff_bits=15) == 255).all() and (oracle.gray_u8(full, coeff_bits=14) == 255).all()
 
 
 def test_layout_matches_survey(oracle):

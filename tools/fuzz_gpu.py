@@ -112,12 +112,12 @@ while time.time() < t_end:
         stride = 3 * w + int(rng.choice([0, 0, 1, 2, 3, 4, 13]))
         raw = np.zeros((h, stride), np.uint8); raw[:, :3 * w] = img.reshape(h, 3 * w)
         order = bool(rng.integers(0, 2))
-        bits = int(rng.choice([14, 14, 15]))                              # reloc_params.gray_coeff_bits
+        bits = int(rng.choice([15, 15, 14]))                              # reloc_params.gray_coeff_bits
         dev = e.dev_alloc(raw.nbytes)
         e.h2d(dev, raw)
         e.set_params(gray_coeff_bits=bits)
         n = e.orb_frame_dev(dev, w, h, stride, order_rgb=order)
-        e.set_params(gray_coeff_bits=14)
+        e.set_params(gray_coeff_bits=15)
         e.dev_free(dev)
         gray = O.gray_u8(img, order, bits)
         pyr = O.pyramid(gray)
