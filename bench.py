@@ -248,23 +248,35 @@ def scan_case(e, L, rows, Qs, seed, forms=(False, True), n=40, preroll=30):
     return out
 
 
-def tick_latency_2hz(e, frames_dev, base_poses, result_row, n_ticks, idle_s, mode, exclusive):
+def tick_latency_2hz(e, frames_dev, base_poses, result_row, n_ticks, idle_s, mode):
     """One synchronous tick every `idle_s` seconds -- the reference's cadence (timer at 2 Hz, M:76): every tick starts on a
-    chip that has been idle for half a second, clocks down.  No pre-roll, nothing hidden; the first tick is dropped."""
+    chip that has been idle for half a second, clocks down.  No pre-roll, nothing hidden.  The two deployment forms -- the
+    context marked exclusive (reloc_set_exclusive: one scan generation, latency shapes) and not -- are INTERLEAVED tick by
+    tick in one loop with the order alternating pair by pair (E N, N E, ...), `n_ticks` of each, so that they see the same
+    chip state (round 3 timed 40 exclusive ticks and then 10 others: the two figures were from different minutes of the
+    box).  The first pair is dropped."""
     e.tick_result_to(result_row)
-    e.set_exclusive(bool(exclusive))
-    ts = []
-    for i in range(n_ticks + 1):
+    ts = {True: [], False: []}
+    order = [True, False]
+    for k in range(n_ticks):
+        order += [True, False] if k % 2 == 0 else [False, True]
+    for i, excl in enumerate(order):
+        e.set_exclusive(excl)
         time.sleep(idle_s)
         result_row[72:76] = 255
         t0 = time.perf_counter()
         e.tick_dev(frames_dev[i % len(frames_dev)], W, H, base_poses[i % len(frames_dev)], False, mode, i)
         e.tick_wait()
-        ts.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
         assert result_row[72] != 255, "tick result record did not arrive"
+        if i >= 2:
+            ts[excl].append(dt)
     e.set_exclusive(False)
-    ts = np.array(ts[1:]) * 1e6
-    return dict(median=float(np.median(ts)), p95=float(np.percentile(ts, 95)), min=float(ts.min()), ticks=n_ticks, idle_s=idle_s)
+
+    def stats(x):
+        x = np.array(x) * 1e6
+        return dict(median=float(np.median(x)), p95=float(np.percentile(x, 95)), min=float(x.min()), ticks=len(x), idle_s=idle_s)
+    return stats(ts[True]), stats(ts[False])
 
 
 def bench_sharded(args, rank, world, local_rank, dist, torch):
@@ -502,7 +514,7 @@ def main(argv=None):
     ap.add_argument("--no-ingest", action="store_true", help="skip the second timed run with frames uploaded from host memory")
     ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames cycled through (each with its own planted record)")
     ap.add_argument("--no-2hz", action="store_true", help="skip the tick latency at the reference's 2 Hz cadence (~50 s of mostly idle time)")
-    ap.add_argument("--ticks-2hz", type=int, default=40)
+    ap.add_argument("--ticks-2hz", type=int, default=24, help="ticks of EACH form (exclusive / not), interleaved, per mode")
     ap.add_argument("--no-extra-scans", action="store_true", help="skip roofline_ragged / roofline_small_q")
     ap.add_argument("--matrix-only", action="store_true",
                     help="BASELINE config 5 shape: the 20000 x 20000 u16 Hamming matrix, row blocks split over the ranks, no\n"
@@ -732,8 +744,10 @@ def main(argv=None):
         # ---- 2 Hz cadence: a tick every 0.5 s, as the reference's timer fires (M:76), each on an idle chip
         if not args.no_2hz:
             for mode, name in ((1, "tick_global"), (0, "tick_local")):
-                lat[name + "_2hz_us"] = tick_latency_2hz(e, frames_dev, base_poses, results[0], args.ticks_2hz, 0.5, mode, True)
-                lat[name + "_2hz_not_exclusive_us"] = tick_latency_2hz(e, frames_dev, base_poses, results[0], max(8, args.ticks_2hz // 4), 0.5, mode, False)
+                lat[name + "_2hz_us"], lat[name + "_2hz_not_exclusive_us"] = tick_latency_2hz(
+                    e, frames_dev, base_poses, results[0], args.ticks_2hz, 0.5, mode)
+            lat["note_2hz"] = ("exclusive and non-exclusive ticks interleaved in one loop, alternating order, same sample size; a local tick "
+                               "launches the same kernel shapes in both forms (reloc_tick.hip: latency shapes for LOCAL ticks)")
         # ---- the scan on the record sizes of real teach databases, and the few-query shape that IS HBM-bound
         roofline_ragged = roofline_small_q = None
         if not args.no_extra_scans:

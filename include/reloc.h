@@ -250,6 +250,11 @@ int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int ord
  * gates per frame.  Results per context as after reloc_tick_dev.  base_poses: n x 7, seeds: n or NULL. */
 int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
                          const double *base_poses, int global_reloc, const uint64_t *seeds);
+/* The result of the last tick enqueued on ctx.  WAITS FOR THAT TICK'S RECORD ONLY (reloc_tick_wait below), not for the stream:
+ * since round 3 this call is no stream barrier -- work enqueued behind the tick (reloc_tick_accumulate_dev, copies, the scan half
+ * of a next frame) may still be running when it returns; call reloc_sync() before touching anything such work writes.  If the
+ * last tick entry point on ctx returned an error before its result record was enqueued, this returns RELOC_E_STATE (it never
+ * hands out the previous tick's record in its place). */
 int reloc_tick_result(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, float *reproj,
                       int32_t *lm_idx, int32_t *outcome, int32_t *n_candidates);
 /* Waits for the result record of the last tick enqueued on ctx -- and only for that: the tick's last kernel stores the
@@ -274,7 +279,8 @@ int reloc_tick_result_to(reloc_ctx *ctx, void *pinned_record);
  * price of ~10 % throughput if several such contexts do run side by side.  `on` == 0: it is not alone.  `on` < 0 (the
  * default): decided per call -- alone while it is the only live context this process has created with reloc_create. */
 int reloc_set_exclusive(reloc_ctx *ctx, int on);
-/* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344). */
+/* Same plus n_features and the `relocating` flag (1 when the whole-database search produced the candidates, G:344); waits like
+ * reloc_tick_result (the tick's record only; RELOC_E_STATE after a tick that failed to enqueue). */
 int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, double *reproj, int32_t *lm_idx,
                          int32_t *outcome, int32_t *n_candidates, int32_t *n_features, int32_t *relocating);
 /* Accumulation (M:435-500), enqueued behind a tick on the same ctx: when the tick's outcome is no_candidates /
@@ -286,9 +292,12 @@ int reloc_tick_result_ex(reloc_ctx *ctx, double anchor_pose[7], int32_t *n_inl, 
 int reloc_tick_accumulate_dev(reloc_ctx *ctx, const uint16_t *depth_mm_dev, int w, int h, const double base_pose[7],
                               int silence_ok);
 int reloc_accumulate_result(reloc_ctx *ctx, int32_t *appended, int32_t *n_kpts, double *nearest_m);
-/* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12).  A candidate whose RANSAC consensus set
- * is smaller than the tick's inlier gate (min_inliers / global_min_inliers) cannot be accepted and is not refined: its record
- * carries the inlier count, the RANSAC pose and reproj 0. */
+/* Parity tap: per-candidate records of the last tick (arrays of 32 entries; Rt 32 x 12).  Three shapes, by what the tick's inlier
+ * gate (min_inliers; global_min_inliers in a whole-database search) lets a candidate become:
+ *   consensus set >= gate         refined: ok 1, n_inl, the refined pose, reproj = mean reprojection error of the inliers
+ *   matches >= gate > consensus   cannot be accepted, not refined: ok as RANSAC left it, n_inl = the consensus size, the RANSAC pose, reproj 0
+ *   matches < gate                no hypothesis is drawn at all (its consensus set cannot reach the gate): ok 0, n_inl 0, reproj 0
+ * With the gate at 0 every candidate takes the first shape (tests/test_gpu_tick.py::test_inlier_gate_shapes_of_the_parity_tap). */
 int reloc_tick_debug(reloc_ctx *ctx, int32_t *cand_ids, int32_t *n_cand, int32_t *n_matches,
                      int32_t *n_inl, int32_t *ok, double *reproj, double *Rt);
 /* Sharded database (one rank per GPU): per-record mutual-match counts are local; the caller

@@ -11,8 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RELOC_LIB: developer switch used by tools/exp_scan_variants.py to time experimental builds of the same library
-LIB_PATH = os.environ.get("RELOC_LIB") or os.path.join(_HERE, "csrc", "libreloc_hip.so")
+# RELOC_LIB: developer switch used by tools/exp_*.py to time experimental builds of the same library; like the library's own
+# switches it is honoured only under RELOC_DEV=1
+LIB_PATH = (os.environ.get("RELOC_LIB") if os.environ.get("RELOC_DEV") == "1" else None) or os.path.join(_HERE, "csrc", "libreloc_hip.so")
 
 c_ctx = C.c_void_p
 P = C.c_void_p
@@ -149,7 +150,7 @@ def load(strict: bool = True):
             continue
         fn.restype = res
         fn.argtypes = args
-    if missing and strict and not os.environ.get("RELOC_DEV_PARTIAL"):
+    if missing and strict:
         raise RelocError(f"{LIB_PATH} lacks symbols declared in include/reloc.h: {missing}")
     _lib = lib
     return lib

@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 def build_variant(name: str, defines: list[str], verbose: bool = False) -> str:
     """Developer builds for kernel experiments: the whole library compiled with extra -D flags into
     build_variants/libreloc_hip_<name>.so (git-ignored, travels to the GPU box).  Never loaded by the product path;
-    tools/exp_scan_variants.py selects one through RELOC_LIB."""
+    tests/dev/exp_scan_variants.py and tools/exp_*.py select one through RELOC_LIB (under RELOC_DEV=1)."""
     vdir = os.path.join(HERE, "..", "build_variants", name)
     os.makedirs(vdir, exist_ok=True)
     objs, jobs = [], []

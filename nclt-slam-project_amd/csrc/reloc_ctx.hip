@@ -144,12 +144,17 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
     c->prm.accum_depth_max_m = RELOC_ACCUM_DEPTH_MAX_M;
     c->prm.gray_coeff_bits = RELOC_GRAY_DEFAULT_BITS;     // OpenCV 4.x set (reloc_spec.h)
     c->prm.reserved0 = 0;
-    if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);   // developer switches
-    if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
-    if (const char *e = getenv("RELOC_SCAN_NW")) c->scan_nw = atoi(e);
-    if (const char *e = getenv("RELOC_SCAN_BATCH_GENS")) c->scan_batch_gens = atoi(e);
-    if (const char *e = getenv("RELOC_SCAN_QUOTA_ROWS")) c->scan_quota_rows = atoi(e);
-    if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
+    // Developer switches (tools/exp_*, one test): read ONLY when RELOC_DEV=1 is set, once, here.  A deployment's environment
+    // cannot change the library's behaviour by accident; none of them changes a result.
+    if (const char *dev = getenv("RELOC_DEV"); dev && dev[0] == '1' && dev[1] == 0) {
+        if (const char *e = getenv("RELOC_SCAN_GRID")) c->scan_grid = atoi(e);
+        if (const char *e = getenv("RELOC_SCAN_GENS")) c->scan_gens = atoi(e);
+        if (const char *e = getenv("RELOC_SCAN_NW")) c->scan_nw = atoi(e);
+        if (const char *e = getenv("RELOC_SCAN_BATCH_GENS")) c->scan_batch_gens = atoi(e);
+        if (const char *e = getenv("RELOC_SCAN_QUOTA_ROWS")) c->scan_quota_rows = atoi(e);
+        if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
+        if (const char *e = getenv("RELOC_FAST_GRID")) c->fast_grid = atoi(e);
+    }
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);
         return nullptr;

@@ -54,6 +54,10 @@ constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps t
 // phase stretches 2-3x (k_pyramid 49 vs 17 us, k_fast_blur 46 vs 16) and the scans of the streams overlap less.  With
 // priority the same instructions are issued, only sooner: 4-stream run 6060 -> 6250 frames/s, single-stream ticks unchanged.
 // -DRELOC_SMALL_PRIO=0 switches it off (A/B builds).
+// Workgroups of the FAST + blur launch of a tick that shares the chip with scans (orb_fast_grid in reloc_orb.hip); -1 = one per tile.
+#ifndef RELOC_FAST_GRID_SHARED
+#define RELOC_FAST_GRID_SHARED (-1)
+#endif
 #ifndef RELOC_SMALL_PRIO
 #define RELOC_SMALL_PRIO 3
 #endif
@@ -269,6 +273,7 @@ struct reloc_ctx {
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
     int scan_batch_gens = 0;         // RELOC_SCAN_BATCH_GENS (developer switch): generations of a batched scan launch
     int scan_quota_rows = 1;         // RELOC_SCAN_QUOTA_ROWS (developer switch): 1 = workgroup budgets in rows + sweepers, 0 = a quota of records (rounds 2-3a)
+    int fast_grid = 0;               // RELOC_FAST_GRID (developer switch): workgroups of k_fast_blur, 0 = by context (orb_fast_grid)
     int scan_nw = 0;                 // RELOC_SCAN_NW (developer switch): waves per record of the whole-database scan (1, 2, 4); 0 = by shape
     uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 
@@ -309,6 +314,8 @@ struct reloc_ctx {
     bool local_two_stage = false;    // developer switch RELOC_LOCAL_TWO_STAGE=1: local candidates by k_topk_part + k_candidates_local
     TickResult *tick_res = nullptr;  // 1
     TickResult *tick_res_host = nullptr;   // the same record in pinned host memory, written by k_tick_finalize
+    bool tick_failed = false;              // the last tick entry point on this context returned an error before its result record was
+                                           // enqueued: reloc_tick_wait / reloc_tick_result* report RELOC_E_STATE instead of the previous tick's record
     int32_t tick_seq = 0;                  // stamp of the last tick enqueued (TickResult.pad[0] of its host records); 0: none yet
     TickResult *tick_res_ext = nullptr;    // caller's pinned record for the next ticks (reloc_tick_result_to), or NULL
 };

@@ -485,8 +485,8 @@ template <int NJ, int NW>
 __device__ __forceinline__ void db_count_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur, int max_rows,
-    int32_t *__restrict__ counts, const ScanMask &mask, u32 *ticket, int quota, int n_bounded, u32 *ticket_pool = nullptr,
-    int pool_frames = 1, int block = -1, int n_blocks = -1)
+    int32_t *__restrict__ counts, const ScanMask &mask, u32 *ticket, int quota, int n_bounded, int col_words,
+    u32 *ticket_pool = nullptr, int pool_frames = 1, int block = -1, int n_blocks = -1)
 {
     // quota / n_bounded: the first n_bounded workgroups of a scan leave once they have served `quota` ROWS (their slots go to
     // whatever waits: with several contexts on the chip another stream's ORB / PnP kernel); their budgets add up to the whole
@@ -504,8 +504,15 @@ __device__ __forceinline__ void db_count_body(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_ids = n_ids_p ? min(*n_ids_p, n_ids_max) : n_ids_max;
     const int ncb = max((C + CB - 1) / CB, 1);
-    u32 *colbuf = lds;                        // 2 x ncb * CB : best (distance << 16 | row) per column, double-buffered
-    u32 *rowkey = colbuf + 2 * ncb * CB;      // max_rows     : best (distance << 16 | column) per row
+    // col_words words of column minima (best distance << 16 | row per column), sized by the host from the CAPACITY of the
+    // current-descriptor buffer (one buffer's worth, at least two column blocks); the kernel knows the COUNT: when two buffers
+    // of ncb blocks fit they are double-buffered (the next record's buffer is cleared while this record's chunks run: two
+    // barriers per record), otherwise one buffer is cleared between the records (three barriers).  A tick's ~500 features in
+    // a context made for 8192 are one block: double-buffered in 33 KB, where sizing two buffers for the capacity took 66 KB
+    // and left room for two workgroups per CU instead of four.
+    const bool dbl = 2 * ncb * CB <= col_words;                                // workgroup-uniform
+    u32 *colbuf = lds;
+    u32 *rowkey = colbuf + col_words;         // max_rows     : best (distance << 16 | column) per row
     u32 *wsum = rowkey + max_rows;            // [0], [1]: mutual-pair counters of the two buffers; [8]: next record
 
     u32 q[NJ][8];
@@ -555,7 +562,7 @@ __device__ __forceinline__ void db_count_body(
     __syncthreads();
     int p = 0;
     while (it < n_ids) {
-        u32 *colbest = colbuf + p * ncb * CB;
+        u32 *colbest = colbuf + (dbl ? p * ncb * CB : 0);
         const int r = rec_ids ? rec_ids[it] : it;
         const bool scored = !(mask.xyh && !heading_ok(mask.xyh + 4 * (int64_t)r, hc, hs, cos_tol));      // workgroup-uniform
         const int64_t row0 = off[r];
@@ -581,7 +588,7 @@ __device__ __forceinline__ void db_count_body(
                     scan_chunk<NJ, 16, true>(rec, n, tc, min(16, tend - tc), q, (u32)(cb * CB), rowkey, colbest, ncb == 1, lane);
             }
         }
-        {   // the other buffer, for the next record
+        if (dbl) {   // the other buffer, for the next record
             u32 *other = colbuf + (p ^ 1) * ncb * CB;
             for (int i = tid; i < ncb * CB; i += 64 * NW) other[i] = 0xFFFFFFFFu;
         }
@@ -605,7 +612,11 @@ __device__ __forceinline__ void db_count_body(
             wsum[p] = 0;
         }
         it = __builtin_amdgcn_readfirstlane((int)wsum[8]);
-        p ^= 1;
+        if (dbl) p ^= 1;
+        else {       // one buffer: cleared between the records
+            for (int i = tid; i < ncb * CB; i += 64 * NW) colbuf[i] = 0xFFFFFFFFu;
+            __syncthreads();
+        }
     }
     if (ticket && tid == 0) {
         const int words = pool_frames * 8;
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
     int32_t *__restrict__ m_qidx, int32_t *__restrict__ m_tidx, int32_t *__restrict__ m_dist,
-    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota, int n_bounded)
+    int32_t *__restrict__ m_n, int emit_stride, ScanMask mask, u32 *ticket, int quota, int n_bounded, int col_words)
 {
     extern __shared__ u32 lds[];
     if constexpr (EMIT) RELOC_SMALL_KERNEL_PRIO();          // the emit pass of a few candidates is one of the tick's small kernels
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
         db_scan_body<NJ, true, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, m_qidx, m_tidx, m_dist, m_n,
                                    emit_stride, mask, ticket, quota);
     else
-        db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota, n_bounded);
+        db_count_body<NJ, NW>(lds, C, db, off, rec_ids, n_ids_p, n_ids_max, cur, max_rows, counts, mask, ticket, quota, n_bounded, col_words);
 }
 
 // The emit pass (match lists of the candidate records, M:327-336) of up to 8 frames in one launch: blockIdx.y = frame.
@@ -701,7 +712,7 @@ struct ScanBatch {
 };
 
 __global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids,
-                                                          int n_cur_max, int max_rows, ScanBatch bt, u32 *ticket_pool, int quota, int n_bounded)
+                                                          int n_cur_max, int max_rows, ScanBatch bt, u32 *ticket_pool, int quota, int n_bounded, int col_words)
 {
     extern __shared__ u32 lds[];
     const int f = blockIdx.x % bt.n;                       // workgroup-uniform
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restric
     mask.skip_if = bt.skip_if[f];
     const int C = bt.n_cur[f] ? min(*bt.n_cur[f], n_cur_max) : n_cur_max;
     db_count_body<8, 4>(lds, C, db, off, nullptr, nullptr, n_ids, bt.cur[f], max_rows, bt.counts[f], mask, ticket_pool + f * 8 * 32, quota,
-                        n_bounded, ticket_pool, bt.n, (int)(blockIdx.x / bt.n), (int)((gridDim.x + bt.n - 1 - f) / bt.n));
+                        n_bounded, col_words, ticket_pool, bt.n, (int)(blockIdx.x / bt.n), (int)((gridDim.x + bt.n - 1 - f) / bt.n));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,83 +828,163 @@ __global__ __launch_bounds__(256, 4) void k_db_ratio(const uint4 *__restrict__ d
 // above wastes its 128 lanes x columns (Q = 1 and Q = 32 both cost the 128-column price, 55 us at 10 000 x 64); here a
 // LANE is a teach row -- the wave reads 64 rows of the record straight from HBM (2 KB, coalesced), the queries are
 // wave-uniform and arrive through the scalar cache -- so the work follows C and the kernel runs at the pace of the
-// database read.  Per 64-row chunk and query: 16 instructions of distance, the row's running best (lane-local key
-// distance << 6 | query: lowest query index on ties), and the query's best row over the 64 lanes, taken 16 queries at
-// a time by the register-tile butterfly rows_min<16> (about 4 instructions per query instead of a 12-instruction wave
-// reduction each).  One wave owns a record (no barriers); its 64 column minima and the record's row keys live in the
-// wave's slice of LDS.  Records of more than SQ_MAX_ROWS rows, emit mode and the heading mask stay with k_db_scan.
+// database read up to Q ~ 8.  One wave owns a record (no barriers); the SIMD's eight waves hide each other's HBM latency
+// (one record per wave turn: taking two or four per turn lets the SIMD's waves fall into step, profiles/r3_small_q_records_per_turn.log).
+// Records of more than SQ_MAX_ROWS rows, emit mode and the heading mask stay with k_db_scan.
 constexpr int SQ_MAX_ROWS = 1024;
 constexpr int SQ_WAVES = 4;
 
-// The same register-tile butterfly as rows_min<R> on keys that fit 16 bits (v_min_u16: full rate; v_min_u32: half rate).
-__device__ __forceinline__ u32 shl6_u16(u32 a)
+// ---- few-query scan, round 4 -------------------------------------------------------------------------------------------
+// Round 4 rebuilt the kernel for fewer instructions per record (round 3's form: profiles/r3_*, git history):
+//   (1) the distances of four queries run as EIGHT accumulator chains (query x descriptor half) in the pinned xor -> bcnt
+//       order of ham8_cols (see there: a v_bcnt must not meet an accumulator written fewer than ~16 instructions earlier);
+//       the two halves are merged and shifted by one v_add_lshl_u32;
+//   (2) the butterfly that takes each query's best row over the 64 lanes is built from v_min_u16 WITH the DPP lane exchange
+//       in the instruction (round 3: v_mov_dpp + two v_cndmask + v_min per node): a node that splits on lane bit 2 or 3 is two
+//       bank-masked DPP minima, on bit 4 or 5 a v_permlane swap and a minimum, and the bits that are left are reduced on ONE
+//       value -- 19 instead of ~36 instructions for 8 queries, 32 instead of ~70 for 16 (sq_bfly);
+//   (3) the best row of every query lives in ONE register (lane sq_lane_of(q) holds query q: the butterfly leaves the
+//       group's minima on every lane whose bits 2.. spell the query, so that lane takes its own), and a row's mutual test
+//       fetches its query's entry with one ds_bpermute: no LDS arrays for records of up to 64 rows, one 16-bit LDS word
+//       per row beyond that.
+// Measured with it and dropped (profiles/r4_small_q_forms.log): requesting record k + 1's rows before record k is worked on
+// (two register sets, loop unrolled by two, the compiler's waits verified as vmcnt(2) in the ISA) -- Q >= 8 unchanged
+// (43.0 vs 43.0 us), Q <= 4 slower (36.3 vs 34.2 us): with eight waves per SIMD the loads were hidden already; what the
+// kernel is short of from Q = 8 on is instruction issue.
+__device__ __forceinline__ u32 add_lshl6(u32 a, u32 b)
 {
     u32 r;
-    asm("v_lshlrev_b16 %0, 6, %1" : "=v"(r) : "v"(a));
+    asm("v_add_lshl_u32 %0, %1, %2, 6" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-template <int K>
-__device__ __forceinline__ u32 bfly16(u32 a, u32 b, int lane)
+
+// hs[j] = distance(query j, row) << 6 for four queries whose words are wave-uniform (SGPRs)
+__device__ __forceinline__ void sq_dist4(const u32 (&qw)[4][8], const u32 (&w)[8], u32 (&hs)[4])
 {
-    if constexpr (K == 32) {
-        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-        return min_u16(r[0], r[1]);
-    } else if constexpr (K == 16) {
-        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-        return min_u16(r[0], r[1]);
-    } else {
-        const bool hi = lane & K;
-        const u32 mine = hi ? b : a;
-        const u32 theirs = hi ? a : b;
-        return min_u16(mine, dpp_xor<K>(theirs));
-    }
-}
-template <int R>
-__device__ __forceinline__ u32 rows_min16(u32 (&d)[R], int lane)
-{
-    if constexpr (R >= 16) {
+    u32 acc[4][2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = bfly16<8>(d[i], d[i + 8], lane);
-    }
-    if constexpr (R >= 8) {
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = bfly16<4>(d[i], d[i + 4], lane);
-    }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) d[i] = bfly16<2>(d[i], d[i + 2], lane);
-    u32 x = bfly16<1>(d[0], d[1], lane);
-    if constexpr (R <= 4) x = min_u16(x, dpp_xor<4>(x));
-    if constexpr (R <= 8) x = min_u16(x, dpp_xor<8>(x));
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-        x = min_u16(r[0], r[1]);
-        const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-        x = min_u16(q[0], q[1]);
-    }
-    return x;
+            for (int h = 0; h < 2; ++h) {
+                u32 x;
+                asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(qw[j][4 * h + k]), "v"(w[4 * h + k]));
+                if (k == 0) asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc[j][h]) : "v"(x));
+                else asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[j][h]) : "v"(x));
+            }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hs[j] = add_lshl6(acc[j][0], acc[j][1]);
 }
 
-// G = queries per butterfly group (4, 8 or 16): a call with 1-4 queries evaluates 4 distances per row, not 16.
-// HOIST (capacity <= G = 4 queries: ONE group): the query words are fetched once per wave and stay in SGPRs (eight queries
-// = 64 SGPRs do not fit beside the loop state: the compiler spills them to VGPR lanes, measured 57 vs 48 us at Q = 8).  Otherwise
-// the queries arrive four at a time, requested together -- round 2 fetched each query through the scalar cache inside the row
-// loop and waited for it, eight dependent round trips per record.
-// Both keys are 16-bit (distance << 6 | query resp. lane, < 2^15): v_lshlrev_b16 / v_or / v_min_u16, all full rate.
-// One wave owns a record; the SIMD's eight waves hide each other's HBM latency.
-template <int G, bool HOIST>
-__global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_db_scan_rows(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec,
-                                                                const uint4 *__restrict__ cur, const int32_t *__restrict__ n_cur_p,
-                                                                int n_cur_max, int32_t *__restrict__ counts)
+// four queries' words (32 SGPRs) by scalar loads at 32-bit byte offsets from the wave-uniform base; indices past the last
+// query repeat it (a duplicate offers the same distance with a larger index: it never wins a minimum)
+__device__ __forceinline__ void sq_load4(const uint4 *__restrict__ cur, int q0, int C, u32 (&qw)[4][8])
 {
-    __shared__ u32 s_col[SQ_WAVES][64];                 // per query: distance << 16 | row of the best row so far
-    __shared__ unsigned short s_row[SQ_WAVES][SQ_MAX_ROWS];   // per row: distance << 6 | query of the best query
+    const char *base = (const char *)cur;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const u32 o = (u32)min(q0 + jj, C - 1) << 5;
+        const uint4 qa = *(const uint4 *)(base + o), qb = *(const uint4 *)(base + o + 16);
+        qw[jj][0] = qa.x; qw[jj][1] = qa.y; qw[jj][2] = qa.z; qw[jj][3] = qa.w;
+        qw[jj][4] = qb.x; qw[jj][5] = qb.y; qw[jj][6] = qb.z; qw[jj][7] = qb.w;
+    }
+}
+
+// Butterfly minimum of G 16-bit keys per lane over the 64 lanes: afterwards EVERY lane l holds the minimum over all lanes of
+// vector j(l) = (l >> 2) & (G - 1).  One asm statement: the order is fixed, so the wait states the hardware does not
+// interlock are counted by hand (a VALU write of a register -> a DPP or v_permlane read of it needs 2 wait states: the
+// producer is never closer than two instructions, or an s_nop 1 stands between; the opening s_nop covers the compiler's
+// instruction in front of the statement).  Nodes:  lane bit 2: bank-masked row_shl:4 / row_shr:4;  bit 3: row_ror:8;
+// bit 4 / 5: v_permlane16/32_swap (a half exchange: one operand's odd halves against the other's even halves) + minimum;
+// bits left over are reduced on the one remaining value (quad_perm for bits 0 and 1; a swap with a copy for bits 4, 5).
+#define SQ_N4(a, b)  "v_min_u16_dpp " a ", " a ", " a " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+                     "v_min_u16_dpp " a ", " b ", " b " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+#define SQ_N8(a, b)  "v_min_u16_dpp " a ", " a ", " a " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                     "v_min_u16_dpp " a ", " b ", " b " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+#define SQ_Q1(a)     "v_min_u16_dpp " a ", " a ", " a " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define SQ_Q2(a)     "v_min_u16_dpp " a ", " a ", " a " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+#define SQ_NOP       "s_nop 1\n\t"
+template <int G>
+__device__ __forceinline__ u32 sq_bfly(u32 (&d)[G])
+{
+    if constexpr (G == 16) {
+        asm volatile(SQ_NOP
+                     SQ_N4("%0", "%1") SQ_N4("%2", "%3") SQ_N4("%4", "%5") SQ_N4("%6", "%7")
+                     SQ_N4("%8", "%9") SQ_N4("%10", "%11") SQ_N4("%12", "%13") SQ_N4("%14", "%15")
+                     SQ_N8("%0", "%2") SQ_N8("%4", "%6") SQ_N8("%8", "%10") SQ_N8("%12", "%14")
+                     "v_permlane16_swap_b32 %0, %4\n\t"              // %4 was written 5 instructions ago
+                     "v_permlane16_swap_b32 %8, %12\n\t"             // %12: the instruction before last + one swap: pad
+                     "v_min_u16 %0, %0, %4\n\t"
+                     "v_min_u16 %8, %8, %12\n\t"
+                     SQ_NOP
+                     "v_permlane32_swap_b32 %0, %8\n\t"
+                     "v_min_u16 %0, %0, %8\n\t"
+                     SQ_NOP SQ_Q1("%0") SQ_NOP SQ_Q2("%0")
+                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
+                       "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+    } else if constexpr (G == 8) {
+        asm volatile(SQ_NOP
+                     SQ_N4("%0", "%1") SQ_N4("%2", "%3") SQ_N4("%4", "%5") SQ_N4("%6", "%7")
+                     SQ_N8("%0", "%2") SQ_N8("%4", "%6")
+                     SQ_NOP
+                     "v_permlane16_swap_b32 %0, %4\n\t"
+                     "v_min_u16 %0, %0, %4\n\t"
+                     SQ_NOP SQ_Q1("%0") SQ_NOP SQ_Q2("%0")
+                     "v_mov_b32 %4, %0\n\t"
+                     SQ_NOP
+                     "v_permlane32_swap_b32 %0, %4\n\t"
+                     "v_min_u16 %0, %0, %4\n\t"
+                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+    } else {
+        static_assert(G == 4, "groups of 4, 8 or 16 queries");
+        asm volatile(SQ_NOP
+                     SQ_N4("%0", "%1") SQ_N4("%2", "%3")
+                     SQ_NOP
+                     SQ_N8("%0", "%2")
+                     SQ_NOP SQ_Q1("%0") SQ_NOP SQ_Q2("%0")
+                     "v_mov_b32 %2, %0\n\t"
+                     SQ_NOP
+                     "v_permlane16_swap_b32 %0, %2\n\t"
+                     "v_min_u16 %0, %0, %2\n\t"
+                     "v_mov_b32 %2, %0\n\t"
+                     SQ_NOP
+                     "v_permlane32_swap_b32 %0, %2\n\t"
+                     "v_min_u16 %0, %0, %2\n\t"
+                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+    }
+    return d[0];
+}
+#undef SQ_N4
+#undef SQ_N8
+#undef SQ_Q1
+#undef SQ_Q2
+#undef SQ_NOP
+// the lane whose register holds query q's entry: bits 2.. = q's place in its group (what sq_bfly leaves there), the group
+// number in the lane bits the butterfly reduced over
+template <int G>
+__device__ __forceinline__ u32 sq_lane_of(u32 q)
+{
+    if constexpr (G == 16) return ((q & 15u) << 2) | (q >> 4);                          // 4 groups: bits 0, 1
+    else if constexpr (G == 8) return ((q & 7u) << 2) | ((q >> 3) & 3u) | (q & 32u);     // 8 groups: bits 0, 1, 5
+    else return (q & 3u) << 2;
+}
+
+template <int G, bool HOIST>
+__global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_db_scan_rows(
+    const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_rec, const uint4 *__restrict__ cur,
+    const int32_t *__restrict__ n_cur_p, int n_cur_max, int32_t *__restrict__ counts)
+{
+    __shared__ unsigned short s_row[SQ_WAVES][SQ_MAX_ROWS];   // per row: distance << 6 | query of the best query (records > 64 rows)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int C = n_cur_p ? min(*n_cur_p, n_cur_max) : n_cur_max;
-    u32 *col = s_col[wave];
     unsigned short *rowk = s_row[wave];
     const int gw = blockIdx.x * SQ_WAVES + wave, nw = gridDim.x * SQ_WAVES;
-    u32 qs[HOIST ? G : 1][8];
+    // the group whose entries this lane keeps (see sq_lane_of): the lane bits the butterfly reduces over
+    const int my_group = G == 16 ? (lane & 3) : (G == 8 ? ((lane & 3) | ((lane >> 5) << 2)) : 0);
+    constexpr int NH = HOIST ? G : 1;
+    u32 qs[NH][8];
     if constexpr (HOIST) {
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -903,97 +994,70 @@ __global__ __launch_bounds__(64 * SQ_WAVES) __attribute__((amdgpu_waves_per_eu(8
             qs[j][4] = qb.x; qs[j][5] = qb.y; qs[j][6] = qb.z; qs[j][7] = qb.w;
         }
     }
-    // first chunk (rows 0..63, lanes past the end repeat the last row) of record r; a record without rows fetches nothing
-    auto fetch0 = [&](int r, int64_t &row0, int &n, uint4 &a, uint4 &b) {
-        row0 = off[r];
-        n = (int)(off[r + 1] - row0);
-        if (n > 0) {
-            const int row = min(lane, n - 1);
-            a = db[2 * (row0 + row)]; b = db[2 * (row0 + row) + 1];
+    // one 64-row chunk (rows tc .. tc + 63 in the lanes) against all queries: updates colk, returns the rows' best queries
+    auto chunk = [&](const uint4 a, const uint4 b, int tc, u32 &colk) -> u32 {
+        const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        u32 rbest = 0xFFFFu;
+        for (int q0 = 0; q0 < (HOIST ? 1 : C); q0 += G) {
+            u32 ck[G];
+#pragma unroll
+            for (int j4 = 0; j4 < G; j4 += 4) {
+                u32 hs[4];
+                if constexpr (HOIST) {
+                    const u32 (&qv)[4][8] = *reinterpret_cast<const u32 (*)[4][8]>(&qs[j4 < NH ? j4 : 0]);
+                    sq_dist4(qv, w, hs);
+                } else {
+                    u32 qw[4][8];
+                    sq_load4(cur, q0 + j4, C, qw);
+                    sq_dist4(qw, w, hs);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    rbest = min_u16(rbest, hs[jj] | (u32)(q0 + j4 + jj));     // distance <= 256: (256 << 6 | 63) < 2^15
+                    ck[j4 + jj] = hs[jj] | (u32)lane;
+                }
+            }
+            const u32 m = sq_bfly<G>(ck);               // EVERY lane l: best (distance, lane) of query q0 + ((l >> 2) & (G - 1)) over the 64 rows
+            const u32 key = ((m >> 6) << 16) | (u32)(tc + (int)(m & 63u));
+            const u32 better = umin(colk, key);
+            colk = my_group * G == q0 ? better : colk;                     // the lane of this group keeps the entry of its query
         }
+        return rbest;
     };
-    // one record; (a, b) = its first 64 rows, already requested
-    auto process = [&](int r, int64_t row0, int n, uint4 a, uint4 b) {
+    for (int r = gw; r < n_rec; r += nw) {
+        const int64_t row0 = off[r];
+        const int n = (int)(off[r + 1] - row0);
         if (n <= 0 || C <= 0) {
             if (lane == 0) counts[r] = 0;
-            return;
+            continue;
         }
-        col[lane] = 0xFFFFFFFFu;
-        for (int tc = 0; tc < n; tc += 64) {
-            if (tc > 0) {                                                  // records of more than 64 rows: further chunks on demand
-                const int row = min(tc + lane, n - 1);
-                a = db[2 * (row0 + row)]; b = db[2 * (row0 + row) + 1];
+        const uint4 *rec = db + 2 * row0;
+        u32 colk = 0xFFFFFFFFu;                          // lane sq_lane_of(q): distance << 16 | row of query q's best row so far
+        // mutual pairs: row t's best query must name t as its best row (lowest index on ties both ways)
+        int total;
+        {
+            const int row = min(lane, n - 1);            // lanes past the end repeat the last row (larger lane index: loses every tie)
+            const u32 rb = chunk(rec[2 * row], rec[2 * row + 1], 0, colk);
+            if (n <= 64) {
+                const u32 peer = (u32)__builtin_amdgcn_ds_bpermute((int)(sq_lane_of<G>(rb & 63u) << 2), (int)colk);
+                total = __popcll(__ballot(lane < n && (peer & 0xFFFFu) == (u32)lane));
+                if (lane == 0) counts[r] = total;
+                continue;
             }
-            const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            u32 rbest = 0xFFFFu;
-            for (int q0 = 0; q0 < (HOIST ? 1 : C); q0 += G) {
-                u32 ck[G];
-#pragma unroll
-                for (int j4 = 0; j4 < G; j4 += 4) {
-                    // four queries at a time: their 32 words are requested together (32 SGPRs; eight at once would not fit the
-                    // scalar register file beside the loop's own state)
-                    u32 qw[4][8];
-                    if constexpr (!HOIST) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int q = min(q0 + j4 + jj, C - 1);      // wave-uniform; repeats of the last query lose every tie (larger index)
-                            const uint4 qa = cur[2 * q], qb = cur[2 * q + 1];
-                            qw[jj][0] = qa.x; qw[jj][1] = qa.y; qw[jj][2] = qa.z; qw[jj][3] = qa.w;
-                            qw[jj][4] = qb.x; qw[jj][5] = qb.y; qw[jj][6] = qb.z; qw[jj][7] = qb.w;
-                        }
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int j = j4 + jj;
-                        u32 h = 0;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) h = bcnt_acc(w[k] ^ (HOIST ? qs[j][k] : qw[jj][k]), h);
-                        const u32 hs = shl6_u16(h);                        // distance <= 256: (256 << 6 | 63) < 2^15
-                        rbest = min_u16(rbest, hs | (u32)(q0 + j));
-                        ck[j] = hs | (u32)lane;
-                    }
-                }
-                const u32 m = rows_min16<G>(ck, lane);  // lane l: best (distance, lane) of query q0 + (l & (G - 1)) over the 64 rows
-                if (lane < G && q0 + lane < C) {
-                    const u32 key = ((m >> 6) << 16) | (u32)(tc + (int)(m & 63u));
-                    if (key < col[q0 + lane]) col[q0 + lane] = key;          // one wave: plain read-modify-write
-                }
-            }
-            if (tc + lane < n) rowk[tc + lane] = (unsigned short)rbest;
+            rowk[lane] = (unsigned short)rb;
         }
-        // mutual pairs: row r's best query must name r as its best row (lowest index on ties both ways)
-        int total = 0;
+        for (int tc = 64; tc < n; tc += 64) {                              // records of more than 64 rows: further chunks
+            const int row = min(tc + lane, n - 1);
+            const u32 rb = chunk(rec[2 * row], rec[2 * row + 1], tc, colk);
+            if (tc + lane < n) rowk[tc + lane] = (unsigned short)rb;
+        }
+        total = 0;
         for (int tc = 0; tc < n; tc += 64) {
-            bool mutual = false;
-            if (tc + lane < n) {
-                const u32 k = rowk[tc + lane];
-                mutual = (col[k & 63u] & 0xFFFFu) == (u32)(tc + lane);
-            }
-            total += __popcll(__ballot(mutual));
+            const u32 k = tc + lane < n ? rowk[tc + lane] : 0u;
+            const u32 peer = (u32)__builtin_amdgcn_ds_bpermute((int)(sq_lane_of<G>(k & 63u) << 2), (int)colk);
+            total += __popcll(__ballot(tc + lane < n && (peer & 0xFFFFu) == (u32)(tc + lane)));
         }
         if (lane == 0) counts[r] = total;
-    };
-    // NT records per turn (all first chunks requested before any is worked on).  ONE is the fastest (100 000 x 64 rows, same
-    // box, profiles/r3_small_q_records_per_turn.log: Q = 8: 43.0 / 45.9 / 49.7 us for 1 / 2 / 4 records per turn, Q = 1: 33.9 /
-    // 35.0 / 37.9): with longer turns the SIMD's eight waves fall into step -- all compute, then all wait for their rows --
-    // while short turns keep some of them at each stage.  (A prefetch carried around the loop does not survive the
-    // compiler: the register copy at the back edge is a use, and its s_waitcnt vmcnt(0) sits in front of the next request.)
-#ifndef ROWS_PER_TURN
-#define ROWS_PER_TURN 1
-#endif
-    constexpr int NT = ROWS_PER_TURN;
-    for (int r = gw; r < n_rec; r += NT * nw) {
-        int64_t row0[NT];
-        int n[NT];
-        uint4 a[NT], b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            row0[t] = 0; n[t] = 0; a[t] = uint4{}; b[t] = uint4{};
-            if (r + t * nw < n_rec) fetch0(r + t * nw, row0[t], n[t], a[t], b[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (r + t * nw < n_rec) process(r + t * nw, row0[t], n[t], a[t], b[t]);
     }
 }
 
@@ -1018,6 +1082,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
 #define RELOC_LAUNCH_ROWS(G, HOIST)                                                                                           \
     hipLaunchKernelGGL((k_db_scan_rows<G, HOIST>), dim3(grid), dim3(64 * SQ_WAVES), 0, ctx->stream, (const uint4 *)db_desc, db_off, n_ids_max, \
                        (const uint4 *)cur, n_cur_dev, n_cur_max, counts)
+        // G = queries per butterfly group: a call with 1-4 queries evaluates 4 distances per row, not 16; its query words stay in SGPRs
         if (n_cur_max <= 4) RELOC_LAUNCH_ROWS(4, true); else if (n_cur_max <= 8) RELOC_LAUNCH_ROWS(8, false); else RELOC_LAUNCH_ROWS(16, false);
 #undef RELOC_LAUNCH_ROWS
         HIP_TRY(hipGetLastError());
@@ -1026,7 +1091,10 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const int nj = n_cur_max <= 128 ? 2 : (n_cur_max <= 256 ? 4 : 8);      // columns per lane, see k_db_scan
     const int cb = 64 * nj;
     const int ncb = (n_cur_max + cb - 1) / cb > 0 ? (n_cur_max + cb - 1) / cb : 1;
-    const size_t lds = (size_t)((m_qidx ? 1 : 2) * ncb * cb + max_rows + 16) * 4;     // the counting scan double-buffers its column minima
+    // column minima: one buffer for the capacity; the counting scan double-buffers inside it when the run-time count leaves room
+    // (db_count_body), so at least two column blocks
+    const int col_words = (m_qidx || ncb >= 2 ? ncb : 2) * cb;
+    const size_t lds = (size_t)(col_words + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
     // Whole-database scans (host-known record count, more records than resident workgroups): workgroups DRAW their records
     // from per-XCD ticket counters instead of a static round-robin deal, so the work stays balanced to the last record
@@ -1050,7 +1118,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         nw = ctx->scan_nw == 1 || ctx->scan_nw == 2 || ctx->scan_nw == 4 ? ctx->scan_nw : 4;
         if (nw == 1 && lds * 16 > 150 * 1024) nw = 2;          // 16 one-wave workgroups per CU have to fit their LDS
     }
-    const int resident = ctx->num_cu * 16 / nw;    // 16 waves per CU (128-VGPR kernel)
+    int wg_per_cu = 16 / nw;                       // 16 waves per CU (128-VGPR kernel) ...
+    if ((size_t)wg_per_cu * lds > 160 * 1024) wg_per_cu = (int)(160 * 1024 / lds);     // ... unless their LDS does not fit
+    const int resident = ctx->num_cu * wg_per_cu;
     int grid = ctx->scan_grid > 0 ? ctx->scan_grid : ctx->num_cu * 16;    // RELOC_SCAN_GRID: developer switch, read at creation
     u32 *ticket = nullptr;
     int quota = 0, n_bounded = 0;
@@ -1080,7 +1150,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
 #define RELOC_LAUNCH_SCAN(NJ, EMIT, NW)                                                                                      \
     hipLaunchKernelGGL((k_db_scan<NJ, EMIT, NW>), dim3(grid), dim3(64 * NW), lds, ctx->stream, (const uint4 *)db_desc, db_off, rec_ids, \
                        n_ids_dev, n_ids_max, (const uint4 *)cur, n_cur_dev, n_cur_max, max_rows, counts, m_qidx, m_tidx, m_dist, \
-                       m_n, emit_stride, mask, ticket, quota, n_bounded)
+                       m_n, emit_stride, mask, ticket, quota, n_bounded, col_words)
     if (m_qidx && ctx->latency_shapes) {
         if (nj == 2) RELOC_LAUNCH_SCAN(2, true, 8); else if (nj == 4) RELOC_LAUNCH_SCAN(4, true, 8); else RELOC_LAUNCH_SCAN(8, true, 8);
     } else if (m_qidx) {
@@ -1116,7 +1186,8 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     const int n_ids = (int)c0->db_records, max_rows = c0->db_max_rows < 1 ? 1 : c0->db_max_rows;
     // n_cur_max = the feature capacity; the 8-column kernel walks column blocks of 512 (one block for nfeatures <= 512)
     const int ncb = (c0->max_feat + 511) / 512;
-    const size_t lds_all = (size_t)(2 * ncb * 512 + max_rows + 16) * 4;
+    const int col_words = (ncb >= 2 ? ncb : 2) * 512;         // see launch_db_scan
+    const size_t lds_all = (size_t)(col_words + max_rows + 16) * 4;
     int gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
     if (c0->scan_batch_gens > 0) gens = c0->scan_batch_gens;
     const int resident = c0->num_cu * 4;
@@ -1136,7 +1207,7 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     int nb_arg = n_bounded;
     if (!c0->scan_quota_rows) { quota = q_rec; per_frame = n_bounded; nb_arg = -1; }
     hipLaunchKernelGGL(k_db_scan_batch, dim3(per_frame * n), dim3(256), lds_all, c0->stream, (const uint4 *)c0->db_desc, c0->db_off,
-                       n_ids, c0->max_feat, max_rows, bt, c0->scan_ticket, quota, nb_arg);
+                       n_ids, c0->max_feat, max_rows, bt, c0->scan_ticket, quota, nb_arg, col_words);
     HIP_TRY(hipGetLastError());
     return RELOC_OK;
 }

@@ -614,6 +614,7 @@ __global__ void k_set_flag(int32_t *flag, int v) { *flag = v; }
 static int tick_next_seq(reloc_ctx *ctx)
 {
     ctx->tick_seq = ctx->tick_seq >= 0x7fffffff ? 1 : ctx->tick_seq + 1;
+    ctx->tick_failed = false;                 // called where the finalisation (which stores the record and this stamp) is launched
     return ctx->tick_seq;
 }
 
@@ -738,6 +739,7 @@ static int tick_solve_batch(reloc_ctx *const *ctxs, int n, const double *base_po
 RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int h, int order, const double base_pose[7],
                              int global_reloc, uint64_t seed)
 {
+    if (ctx) ctx->tick_failed = true;         // until the finalisation has been enqueued (tick_next_seq)
     ARG_CHECK_CTX(ctx, img_dev && base_pose && w >= 64 && h >= 64 && global_reloc >= 0 && global_reloc <= 2, "reloc_tick_dev");
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     if (ctx->max_feat > 65535) { reloc_set_error("tick: max_feat must be <= 65535"); return RELOC_E_CAPACITY; }
@@ -751,6 +753,8 @@ RELOC_API int reloc_tick_dev(reloc_ctx *ctx, const uint8_t *img_dev, int w, int 
 RELOC_API int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *imgs_dev, int w, int h, int order,
                                    const double *base_poses, int global_reloc, const uint64_t *seeds)
 {
+    if (ctxs && n >= 1 && n <= 8)
+        for (int f = 0; f < n; ++f) if (ctxs[f]) ctxs[f]->tick_failed = true;
     ARG_CHECK(ctxs && imgs_dev && base_poses && n >= 1 && n <= 8 && w >= 64 && h >= 64 && global_reloc >= 0 && global_reloc <= 2,
               "reloc_tick_batch_dev");
     for (int f = 0; f < n; ++f) {
@@ -796,6 +800,10 @@ RELOC_API int reloc_tick_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t 
 RELOC_API int reloc_tick_wait(reloc_ctx *ctx)
 {
     ARG_CHECK_CTX(ctx, true, "ctx is NULL");
+    if (ctx->tick_failed) {
+        reloc_set_error("reloc_tick_wait: the last tick on this context failed before its result record was enqueued");
+        return RELOC_E_STATE;
+    }
     const int want = ctx->tick_seq;
     if (want == 0 || !ctx->tick_res_host) { HIP_TRY(hipStreamSynchronize(ctx->stream)); return RELOC_OK; }
     volatile int32_t *stamp = (volatile int32_t *)&ctx->tick_res_host->pad[0];
@@ -920,6 +928,7 @@ __global__ void k_set_candidates_batch(const int32_t *__restrict__ ids, int k, S
 RELOC_API int reloc_tick_solve_dev(reloc_ctx *ctx, const int32_t *cand_ids_dev, int n_cand, const double base_pose[7],
                                    int check_consistency, uint64_t seed)
 {
+    if (ctx) ctx->tick_failed = true;
     ARG_CHECK_CTX(ctx, cand_ids_dev && base_pose && n_cand >= 0 && n_cand <= MAX_CAND, "reloc_tick_solve_dev");
     if (!db_ready(ctx)) { reloc_set_error("no database uploaded"); return RELOC_E_STATE; }
     hipLaunchKernelGGL(k_set_candidates, dim3(1), dim3(64), 0, ctx->stream, cand_ids_dev, n_cand, ctx->cand_ids, ctx->cand_n);
@@ -1027,6 +1036,8 @@ RELOC_API int reloc_shard_merge_dev(reloc_ctx *ctx, const int32_t *all_scan_dev,
 RELOC_API int reloc_shard_solve_batch_dev(reloc_ctx *const *ctxs, int n, const int32_t *cand_local_dev, int k,
                                           const double *base_poses, const uint64_t *seeds, void *res_out)
 {
+    if (ctxs && n >= 1 && n <= 8)
+        for (int f = 0; f < n; ++f) if (ctxs[f]) ctxs[f]->tick_failed = true;
     int rc = shard_batch_check(ctxs, n, "reloc_shard_solve_batch_dev");
     if (rc) return rc;
     ARG_CHECK(cand_local_dev && base_poses && res_out && k > 0 && k <= MAX_CAND, "reloc_shard_solve_batch_dev");

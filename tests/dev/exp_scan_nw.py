@@ -1,9 +1,9 @@
 """Developer experiment (round 3): waves per record of the whole-database scan (RELOC_SCAN_NW = 4 / 2 / 1) on fixed and ragged
 databases, each checked against the CPU oracle first; one subprocess per setting.
-    python tools/exp_scan_nw.py            # single-stream kernel times, default grid and one-generation (exclusive) grid
+    python tests/dev/exp_scan_nw.py            # single-stream kernel times, default grid and one-generation (exclusive) grid
 """
 import json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 SHAPES = (("fixed64_10k", "fixed64", 10000), ("ragged_10k", "ragged", 10000), ("45_10k", 45, 10000), ("100_10k", 100, 10000),
@@ -64,5 +64,5 @@ if __name__ == "__main__":
         for rnd in range(int(os.environ.get("EXP_ROUNDS", "1"))):
             for excl in ("0", "1"):
                 for nw in os.environ.get("EXP_NWS", "4,2,1").split(","):
-                    env = dict(os.environ, RELOC_SCAN_NW=nw, EXP_EXCLUSIVE=excl)
+                    env = dict(os.environ, RELOC_DEV="1", RELOC_SCAN_NW=nw, EXP_EXCLUSIVE=excl)
                     subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, timeout=900)

@@ -1,9 +1,9 @@
 """Developer experiment: time build variants of libreloc_hip.so (nclt-slam-project_amd/build.py build_variant) on the
 whole-database scan shapes, after checking each against the CPU oracle.  One subprocess per library (RELOC_LIB).
-    python tools/exp_scan_variants.py [lib.so ...]        # default: csrc/libreloc_hip.so + build_variants/*.so
+    python tests/dev/exp_scan_variants.py [lib.so ...]        # default: csrc/libreloc_hip.so + build_variants/*.so
 """
 import glob, json, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
@@ -62,6 +62,6 @@ if __name__ == "__main__":
             sorted(glob.glob(os.path.join(ROOT, "build_variants", "*.so")))
         for lib in libs:
             for grid in os.environ.get("EXP_GRIDS", "0").split(","):        # RELOC_SCAN_GRID values: 0 ticket, -1 static default
-                env = dict(os.environ, RELOC_LIB=os.path.abspath(lib), RELOC_SCAN_GRID=grid)
+                env = dict(os.environ, RELOC_DEV="1", RELOC_LIB=os.path.abspath(lib), RELOC_SCAN_GRID=grid)
                 print(json.dumps(dict(lib=os.path.basename(lib), RELOC_SCAN_GRID=grid)), flush=True)
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--one", lib], env=env, timeout=600)

@@ -1,8 +1,9 @@
 """Randomized parity campaign: HIP library vs CPU oracle on random shapes (developer tool, needs a GPU).
-    python tools/fuzz_gpu.py --seconds 240 --seed 1
+    python tests/dev/fuzz_gpu.py --seconds 240 --seed 1 [--kinds db_small,db]
+(lives under tests/: it checks against the CPU oracle, which only test code may import)
 Exits non-zero on the first mismatch and prints the reproducing seed/case."""
 import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from nclt_slam_project_amd import synth
 from nclt_slam_project_amd.engine import Engine
@@ -11,6 +12,7 @@ from oracle import oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--kinds", default="", help="comma-separated subset of the case kinds (default: all)")
 args = ap.parse_args()
 O.build()
 e = Engine(0, 1280, 720, 8192)
@@ -38,7 +40,7 @@ while time.time() < t_end:
     if time.time() > t_report:                    # a progress line per minute (a silent GPU job is taken to be hung)
         print("progress", sum(n_case.values()), "cases", flush=True)
         t_report = time.time() + 60
-    kind = rng.choice(list(n_case))
+    kind = rng.choice([k for k in n_case if not args.kinds or k in args.kinds.split(",")])
     n_case[kind] += 1
     if kind == "match":
         nq, nt = int(rng.integers(1, 700)), int(rng.integers(1, 1600))

@@ -94,6 +94,62 @@ def test_db_match_counts(engine, oracle, L, nmode, Q):
     assert got.max() >= 20
 
 
+def _few_query_db(rng, low_entropy):
+    """records of every size class the lane-per-row kernel distinguishes: empty, 1 row, below / at / above one 64-row chunk, two
+    and three chunks, the 1024-row limit; more records than one wave turn of the grid"""
+    sizes = [0, 1, 2, 31, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 500, 1023, 1024, 0, 64, 64]
+    n = np.array(sizes + list(rng.integers(0, 140, 900)), np.int64)
+    off = np.zeros(len(n) + 1, np.int64); off[1:] = np.cumsum(n)
+    db = _desc(rng, int(off[-1]))
+    if low_entropy:                                   # few distinct bits: massive distance ties in both directions
+        db &= 0x11
+    return n, off, db
+
+
+@pytest.mark.parametrize("low_entropy", [False, True])
+def test_few_query_scan_every_query_count(engine, oracle, low_entropy):
+    """k_db_scan_rows (<= 64 current descriptors; groups of 4 / 8 / 16 queries, the DPP butterfly, the register-resident
+    column minima and their lane mapping, records of one and of several 64-row chunks): every query count 1..64 against the
+    oracle, with planted matches and with massive ties; then the device-side query count (n_cur on the device smaller than
+    the capacity the launch was shaped for)."""
+    rng = np.random.default_rng(64 + low_entropy)
+    n, off, db = _few_query_db(rng, low_entropy)
+    L = len(n)
+    engine.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
+    for Q in range(1, 65):
+        cur = _desc(rng, Q)
+        if low_entropy:
+            cur &= 0x11
+        else:                                         # planted true matches in a few records, as many as fit
+            dbq = db.copy()
+            for r in rng.choice(L, 6, replace=False):
+                k = int(min(n[r], Q))
+                if k:
+                    dbq[off[r]:off[r] + k] = _planted(rng, cur[rng.choice(Q, k, replace=False)])
+            engine.db_upload(dbq, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
+        got = engine.db_match_counts(cur)
+        exp = oracle.db_match_counts(dbq if not low_entropy else db, off, cur)
+        np.testing.assert_array_equal(got, exp, err_msg=f"Q={Q}")
+        assert got[0] == 0 and got[17] == 0           # the empty records
+    # device-side count: capacity 64 (16-query groups), 5 / 17 / 33 queries really there; capacity 8, 3 there; count 0
+    cur = _desc(rng, 64)
+    if low_entropy:
+        cur &= 0x11
+    dbx = dbq if not low_entropy else db
+    cur_dev = engine.to_device(cur)
+    cnt_dev = engine.dev_alloc(L * 4)
+    ncur_dev = engine.dev_alloc(4)
+    for cap, real in ((64, 5), (64, 17), (64, 33), (8, 3), (4, 1), (64, 0)):
+        engine.h2d(ncur_dev, np.array([real], np.int32))
+        engine.db_match_counts_dev(cur_dev, cap, cnt_dev, ncur_dev)
+        engine.sync()
+        got = np.empty(L, np.int32); engine.d2h(got, cnt_dev)
+        exp = oracle.db_match_counts(dbx, off, cur[:real]) if real else np.zeros(L, np.int32)
+        np.testing.assert_array_equal(got, exp, err_msg=f"capacity {cap}, {real} on the device")
+    for p_ in (cur_dev, cnt_dev, ncur_dev):
+        engine.dev_free(p_)
+
+
 @pytest.mark.parametrize("na,nb", [(1, 8), (3, 5), (130, 2048), (257, 2056), (64, 1001), (1000, 4096)])
 def test_hamming_matrix(engine, oracle, na, nb):
     rng = np.random.default_rng(na * 31 + nb)

@@ -34,5 +34,5 @@ if __name__ == "__main__":
         for lib in sys.argv[1:] or [""]:
             env = dict(os.environ)
             if lib:
-                env["RELOC_LIB"] = os.path.abspath(lib)
+                env["RELOC_DEV"] = "1"; env["RELOC_LIB"] = os.path.abspath(lib)
             subprocess.run([sys.executable, __file__, "--one"], env=env, check=False)

@@ -42,4 +42,4 @@ if __name__ == "__main__":
         spec = importlib.util.spec_from_file_location("reloc_build", os.path.join(ROOT, "nclt-slam-project_amd", "build.py"))
         b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
         lib = b.build_variant("pnp_timing", ["RELOC_PNP_TIMING"])
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, RELOC_LIB=lib, RELOC_DEV_PARTIAL="1"), check=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, RELOC_DEV="1", RELOC_LIB=lib, RELOC_DEV="1"), check=True)

@@ -1,5 +1,7 @@
-"""Developer experiment (round 3): the few-query scan (k_db_scan_rows) of several library builds in ONE run, rounds
-interleaved (boxes of the pool differ by up to 10 %, so only same-run comparisons count).
+"""Developer experiment (rounds 3-4): the few-query scan (k_db_scan_rows / k_db_scan_rows2) of several library builds and / or
+kernel forms (RELOC_SQ_FORM, EXP_FORMS=0,1,2,3) in ONE run, rounds interleaved (boxes of the pool differ by up to 10 %, so only
+same-run comparisons count).  Every form's counts are compared with form 0's (the round-3 kernel, which the test-suite holds
+to the oracle) on every database and query count before it is timed.
     python tools/exp_small_q.py [lib.so ...]      # default: csrc/libreloc_hip.so + build_variants/*.so
 """
 import glob, json, os, subprocess, sys
@@ -13,14 +15,28 @@ def one():
     from nclt_slam_project_amd import synth
     e = Engine(0, 640, 480, 4096)
     rng = np.random.default_rng(11)
-    res = dict(lib=os.path.basename(os.environ.get("RELOC_LIB", "product")))
-    for name, rows, L in (("fixed64_100k", "fixed64", 100000), ("ragged_100k", "ragged", 100000)):
+    res = dict(lib=os.path.basename(os.environ.get("RELOC_LIB", "product")), form=os.environ.get("RELOC_SQ_FORM", "0"))
+    ref = None
+    if res["form"] != "0":                       # a second context of this process cannot differ in form (read at creation): the
+        ref = {}                                 # reference counts come from a child that runs form 0 and saves them
+    qs = [int(x) for x in os.environ.get("EXP_QS", "1,4,8,16,32").split(",")]
+    dbs = (("fixed64_100k", "fixed64", 100000), ("ragged_100k", "ragged", 100000), ("fixed64_10k", "fixed64", 10000))
+    for name, rows, L in dbs:
         desc, pts, off, poses = synth.descriptor_db(rng, L, rows)
         e.db_upload(desc, pts, off, poses)
         T = int(off[-1])
         cnt = e.dev_alloc(L * 4)
-        for Q in (1, 4, 8, 16, 32):
+        for Q in qs:
             cur = e.to_device(synth.random_descriptors(rng, Q))
+            e.db_match_counts_dev(cur, Q, cnt)
+            e.sync()
+            got = np.empty(L, np.int32); e.d2h(got, cnt)
+            path = os.path.join(os.environ.get("EXP_REF_DIR", "/tmp"), f"sq_ref_{name}_Q{Q}.npy")
+            if res["form"] == "0":
+                np.save(path, got)
+            elif os.path.exists(path):
+                res.setdefault("parity", True)
+                res["parity"] = bool(res["parity"] and np.array_equal(got, np.load(path)))
             for _ in range(60):
                 e.db_match_counts_dev(cur, Q, cnt)
             e.sync()
@@ -45,7 +61,9 @@ if __name__ == "__main__":
     else:
         libs = sys.argv[1:] or [os.path.join(ROOT, "nclt-slam-project_amd", "csrc", "libreloc_hip.so")] + \
             sorted(glob.glob(os.path.join(ROOT, "build_variants", "*.so")))
+        forms = os.environ.get("EXP_FORMS", "0").split(",")
         for rnd in range(int(os.environ.get("EXP_ROUNDS", "2"))):
             for lib in libs:
-                env = dict(os.environ, RELOC_LIB=os.path.abspath(lib))
-                subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, timeout=600)
+                for form in forms:
+                    env = dict(os.environ, RELOC_DEV="1", RELOC_LIB=os.path.abspath(lib), RELOC_SQ_FORM=form)
+                    subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, timeout=600)

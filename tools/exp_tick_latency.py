@@ -52,4 +52,4 @@ if __name__ == "__main__":
             sorted(glob.glob(os.path.join(ROOT, "build_variants", "*.so")))
         for rnd in range(2):
             for lib in libs:
-                subprocess.run([sys.executable, os.path.abspath(__file__), "--one", lib], env=dict(os.environ, RELOC_LIB=os.path.abspath(lib)), timeout=600)
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--one", lib], env=dict(os.environ, RELOC_DEV="1", RELOC_LIB=os.path.abspath(lib)), timeout=600)
