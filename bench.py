@@ -191,10 +191,10 @@ def cpu_baseline(frames, db, n_frames=112, n_warm=16):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r3/summary.json, else pmc_r2 / pmc_r1e: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_r4/summary.json, else pmc_r3 / pmc_r2 / pmc_r1e: FETCH_SIZE and
     WRITE_SIZE collected in separate passes, handled as MI355X_MICROARCH.md's HBM section prescribes); None if absent."""
     d = None
-    for rnd in ("pmc_r3", "pmc_r2", "pmc_r1e"):
+    for rnd in ("pmc_r4", "pmc_r3", "pmc_r2", "pmc_r1e"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", rnd, "summary.json")))[kernel]
             break
@@ -761,7 +761,7 @@ def main(argv=None):
                                         "VALU-bound like the headline kernel: compare valu.pairs_per_s")
             sq = scan_case(ex, 100000, "fixed64", (1, 8, 32), SEED + 12)
             for r_ in sq:
-                r_["traffic"] = pmc_traffic({1: "k_db_scan_rows_q1", 8: "k_db_scan_rows_q8"}.get(r_["Q"], "-"))
+                r_["traffic"] = pmc_traffic({1: "k_db_scan_rows_q1", 8: "k_db_scan_rows_q8", 32: "k_db_scan_rows_q32"}.get(r_["Q"], "-"))
             roofline_small_q = dict(sq[0], workload="100000 records x 64 rows (205 MB), Q = 1: the variant-G scan shape with few current descriptors "
                                                     "(G:329-344), the HBM-bound match shape", by_Q={str(r["Q"]): r for r in sq})
             ex.close()

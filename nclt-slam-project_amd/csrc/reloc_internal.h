@@ -56,7 +56,7 @@ constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps t
 // -DRELOC_SMALL_PRIO=0 switches it off (A/B builds).
 // Workgroups of the FAST + blur launch of a tick that shares the chip with scans (orb_fast_grid in reloc_orb.hip); -1 = one per tile.
 #ifndef RELOC_FAST_GRID_SHARED
-#define RELOC_FAST_GRID_SHARED (-1)
+#define RELOC_FAST_GRID_SHARED 512
 #endif
 #ifndef RELOC_SMALL_PRIO
 #define RELOC_SMALL_PRIO 3

@@ -19,7 +19,7 @@
 // (s_load_dwordx8, the fetch of row t+1 issued as soon as row t has landed) and feed the VALU as
 // SGPR operands, so one 32-byte scalar fetch pays for 512 pairs and no LDS traffic is in the
 // inner loop.  A record's rows are dealt to the 4 waves of a workgroup as balanced contiguous
-// ranges, walked in 16-row chunks (4-row chunks at the end).  Per chunk a wave produces (a) per lane and column the best row
+// ranges, walked in 16-row chunks and finished with ONE flexible chunk of 1-15 rows.  Per chunk a wave produces (a) per lane and column the best row
 // (running 16-bit minimum), merged into LDS with ds_min_u32, and (b) per row the best column:
 // an in-lane 8-way 16-bit minimum, then a register-tile butterfly across lanes
 // (v_permlane16_swap / ds_bpermute).  Mutual nearest neighbours are resolved in LDS; the kernel
@@ -193,10 +193,7 @@ template <int NJ, int R, bool FLEX>
 __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n, int tc, int nr, const u32 (&q)[NJ][8],
                                            u32 colbase, u32 *rowkey, u32 *colbest, bool single_cb, int lane)
 {
-    // (Measured and dropped in round 3: the running best row of every column kept in a per-wave slice of LDS and updated with
-    // ds_min_u32, one LDS instruction per column and row, instead of v_min_u16 in registers -- one VALU instruction less
-    // per pair, 19.1 instead of 20.1, bit-identical: 154.4 / 156.2 vs 150.4 / 153.5 us at 10 000 records, 1305 vs 1302 us at
-    // 100 000, profiles/r3_scan_lds_colmin.log.  The LDS instruction costs the wave an issue turn all the same.)
+    // (column minima in LDS instead of registers: measured and dropped, profiles/README.md "Dropped experiments" #1)
     u32 cb16[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
@@ -212,10 +209,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     auto row_of = [&](int i) { const int t = bitrev(i); return FLEX ? min(tc + t, n - 1) : tc + t; };   // wave-uniform
     uint4 a = rec[2 * row_of(0)], b = rec[2 * row_of(0) + 1];
     // compile-time row and column indices: the key constants are immediates.
-    // (Measured and dropped: row i-1's bookkeeping software-pipelined INTO row i's distance chains, one 16-bit instruction
-    // in every second xor/bcnt slot, all pinned with asm volatile -- behind the bcnt: 164.9 vs 163.7 us at 10 000 records,
-    // 1410 vs 1368 us at 100 000; between the xor and its bcnt, where the plain form has the compiler's s_nop: 163.8 vs
-    // 161.1 and 1381 vs 1358.  Full-rate instructions are not free between half-rate v_bcnt.)
+    // (bookkeeping software-pipelined into the next row's chains: measured and dropped, profiles/README.md "Dropped experiments" #2)
     static_for<R>([&](auto ic_) {
         constexpr int i = decltype(ic_)::value;
         constexpr int t = [](int v) { int r = 0; for (int bb = 0; bb < LOG_R; ++bb) r |= ((v >> bb) & 1) << (LOG_R - 1 - bb); return r; }(i);
@@ -288,11 +282,8 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
 // otherwise every wave walks all column blocks and reloads its registers per block.
 // mask.xyh != NULL: heading-incompatible records are not scored (count 0), see ScanMask.
 // NJ = 8 is the working point (500 descriptors are one block, 64 VGPRs of descriptors, 4 waves per SIMD);
-// NJ = 4 / 2 serve calls with at most 256 / 128 current descriptors, see k_db_scan.  (NJ = 4 with two blocks and 8 waves per SIMD for 500 descriptors was measured slower, 188 vs 176 us.)
-// Measured and dropped in round 2 (same box, interleaved; profiles/r2_scan_variants.log, last group): the current
-// descriptors kept ONCE per workgroup in LDS (two conflict-free 16-byte planes) and streamed column by column against 4-8
-// teach rows held in SGPRs -- 58 VGPRs, 8 waves per SIMD, 512-thread workgroups, same 20 instructions per pair: 176 vs
-// 170 us at 10 000 records, 1533 vs 1497 us at 100 000.  Occupancy is not what holds this kernel back.
+// NJ = 4 / 2 serve calls with at most 256 / 128 current descriptors, see k_db_scan.  (8 waves per SIMD -- NJ = 4 with two blocks,
+// or the descriptors in LDS -- measured slower: profiles/README.md "Dropped experiments" #3.)
 template <int NJ, bool EMIT, int NW = 4>
 __device__ __forceinline__ void db_scan_body(
     u32 *lds, int C, const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
@@ -492,11 +483,8 @@ __device__ __forceinline__ void db_count_body(
     // whatever waits: with several contexts on the chip another stream's ORB / PnP kernel); their budgets add up to the whole
     // database, so they normally serve every record.  The eight workgroups behind them (one per XCD, the last to start) draw
     // until the counters run dry: whatever the budgets left over is served (nothing, when the host knew the row total).
-    // Rounds 2-3a dealt a quota of RECORDS (n_bounded < 0 still does, RELOC_SCAN_QUOTA_ROWS=0): on ragged databases a workgroup
-    // that drew four long records outlived its generation -- N(60,25) rows, scan alone 180 us against 156 us in one generation;
-    // with row budgets 167 us, and the 4-stream run on 64-row records 6 700 against 6 650 frames/s (on ragged records 6 360
-    // against 6 450).  Measured and dropped on the way (profiles/r3_scan_quota.log): a whole last generation without a budget
-    // balances the tail best (163 us) but holds its slots for a third of the scan, 4 streams lose 5 %; one sweeper per CU: 2.5 %.
+    // (n_bounded < 0: the record quota of rounds 2-3a, RELOC_SCAN_QUOTA_ROWS=0; numbers and the variants dropped on the way:
+    // profiles/README.md "Dropped experiments" #4)
     if (!ticket_pool) ticket_pool = ticket;
     if (block < 0) { block = blockIdx.x; n_blocks = gridDim.x; }
     constexpr int CB = 64 * NJ;
@@ -847,10 +835,7 @@ constexpr int SQ_WAVES = 4;
 //       group's minima on every lane whose bits 2.. spell the query, so that lane takes its own), and a row's mutual test
 //       fetches its query's entry with one ds_bpermute: no LDS arrays for records of up to 64 rows, one 16-bit LDS word
 //       per row beyond that.
-// Measured with it and dropped (profiles/r4_small_q_forms.log): requesting record k + 1's rows before record k is worked on
-// (two register sets, loop unrolled by two, the compiler's waits verified as vmcnt(2) in the ISA) -- Q >= 8 unchanged
-// (43.0 vs 43.0 us), Q <= 4 slower (36.3 vs 34.2 us): with eight waves per SIMD the loads were hidden already; what the
-// kernel is short of from Q = 8 on is instruction issue.
+// (Requesting the next record's rows one record ahead: measured and dropped, profiles/README.md "Dropped experiments" #5.)
 __device__ __forceinline__ u32 add_lshl6(u32 a, u32 b)
 {
     u32 r;
@@ -1097,20 +1082,13 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     const size_t lds = (size_t)(col_words + max_rows + 16) * 4;
     if (lds > 160 * 1024) { reloc_set_error("db scan: LDS demand %zu bytes", lds); return RELOC_E_CAPACITY; }
     // Whole-database scans (host-known record count, more records than resident workgroups): workgroups DRAW their records
-    // from per-XCD ticket counters instead of a static round-robin deal, so the work stays balanced to the last record
-    // (measured r2, one stream, L = 10 000 x 64: 168.5 vs 171.0 us, L = 100 000: 1499 vs 1547 us with ONE resident
-    // generation of workgroups).  But one generation that lives as long as the launch starves the other streams of a
-    // multi-context run: their small kernels get no CU until the scan drains (bench.py, 4 streams: 4800 frames/s against
-    // 5050 with r1's static 16-workgroups-per-CU grid, same box).  So a workgroup serves a QUOTA of records and leaves:
-    // the grid holds a few generations and the deal is still dynamic -- with 6 generations 5110-5200 frames/s in the same runs
-    // (2 / 3 / 4 / 6 / 8 / 12 / 16 generations: 4890 / 4890 / 5030 / 5160 / 5100 / 4960 / 5090; profiles/r2_scan_generations.log).
-    // The price is the descriptor prologue once per workgroup: the scan alone takes 175 instead of 170 us (RELOC_SCAN_GENS=-1 =
-    // one generation, the fastest form for a single stream; reloc_set_exclusive selects it).
-    // Since the small kernels run at wave priority 3 (RELOC_SMALL_KERNEL_PRIO) they need fewer free slots to keep up, and
-    // THREE generations are the optimum: 2 / 3 / 4 / 6 / 8 / 12: 6535 / 6555 / 6390 / 6260 / 6265 / 5890 frames/s, one
-    // generation 5890 (profiles/r2_scan_generations_prio.log).
-    // The short records of the 128-column kernel do not cover the draw latency (Q <= 32: 66 vs 55 us): static there, as
-    // for candidate lists and single records.
+    // from per-XCD ticket counters instead of a static round-robin deal, so the work stays balanced to the last record.  One
+    // resident generation that lives as long as the launch is the fastest form alone but starves the other streams of a
+    // multi-context run, so beside other streams a workgroup serves a budget and leaves: the grid holds THREE generations (the
+    // small kernels run at wave priority 3, RELOC_SMALL_KERNEL_PRIO, and need few free slots); reloc_set_exclusive / a process's
+    // only context selects the one-generation form.  Candidate lists, single records and the 128-column kernel (its short
+    // records do not cover the draw latency) are dealt statically.  Measurements behind each choice: profiles/README.md
+    // "Dropped experiments" #6.
     // Waves per record of the counting scan (NW): 4 waves share a record's rows (finest grain: shortest tail of the launch),
     // or 2, or ONE wave owns a record (no row left for a second chunk epilogue, no barrier that waits for anybody).
     int nw = 4;

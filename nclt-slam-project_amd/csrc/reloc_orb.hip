@@ -455,7 +455,8 @@ __device__ __forceinline__ void fast_nms_tile(const OrbTable *__restrict__ tab, 
     __syncthreads();
     // segment test for every pixel of the tile + 1-px ring; the few corners are compacted into a list so that
     // the score (as long as the test itself) runs on full waves of corners instead of on every wave that
-    // happens to contain one
+    // happens to contain one.  (Compacting the pretest survivors as well, so that the segment test too runs on full waves:
+    // 21 % fewer instructions and no faster -- profiles/README.md "Dropped experiments" #7.)
     const int SS = FT + 4;
     if (tid == 0) s_nc = 0;
     __syncthreads();

@@ -1,8 +1,8 @@
 # Collects the judged evidence of a round on the GPU box (run through gpurun; writes under gpurun_out/<round>/, the
 # summaries are copied into profiles/ by tools/copy_round_evidence.sh afterwards).
-#   usage: bash tools/collect_round_evidence.sh r3 [part]      part: all (default) | core | extra
+#   usage: bash tools/collect_round_evidence.sh r4 [part]      part: all (default) | core | extra
 set -e
-R=${1:-r3}; PART=${2:-all}
+R=${1:-r4}; PART=${2:-all}
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 O=gpurun_out/$R; mkdir -p $O
 NOX="--no-cpu-baseline --no-ingest --no-2hz --no-extra-scans"

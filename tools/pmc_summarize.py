@@ -12,7 +12,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 KERNELS = {"k_db_scan": r"k_db_scan<(8, )?false(, 4)?>", "k_hamming_matrix": r"k_hamming_matrix\(",
-           "k_db_scan_rows_q1": r"k_db_scan_rows<4, ", "k_db_scan_rows_q8": r"k_db_scan_rows<8, "}
+           "k_db_scan_rows_q1": r"k_db_scan_rows<4, ", "k_db_scan_rows_q8": r"k_db_scan_rows<8, ", "k_db_scan_rows_q32": r"k_db_scan_rows<16, "}
 NAMES = {"FETCH_SIZE": "fetch_size_raw_bytes", "WRITE_SIZE": "write_size_bytes", "SQ_INSTS_VALU": "valu_wave_insts",
          "GRBM_GUI_ACTIVE": "grbm_gui_active_sum", "SQ_WAVE_CYCLES": "sq_wave_cycles", "SQ_WAIT_ANY": "sq_wait_any",
          "SQ_WAIT_INST_ANY": "sq_wait_inst_any", "SQ_ACTIVE_INST_ANY": "sq_active_inst_any", "SQ_WAVES": "waves",
@@ -42,7 +42,7 @@ def main(src, dst):
         out[k] = d
     out["_how"] = ("rocprofv3 --pmc <one group per pass> --kernel-trace --output-format csv -- python3 tools/pmc_target.py; "
                    "tools/pmc_summarize.py; shapes: k_db_scan L=10000 n=64 Q=500 (algorithmic 20,536,000 B), "
-                   "k_hamming_matrix 20000x20000 (algorithmic 801,280,000 B), k_db_scan_rows L=100000 n=64 Q=1 / Q=8 (algorithmic 205,200,032 / 205,200,256 B)")
+                   "k_hamming_matrix 20000x20000 (algorithmic 801,280,000 B), k_db_scan_rows L=100000 n=64 Q=1 / 8 / 32 (algorithmic 205,200,032 / 205,200,256 / 205,201,024 B)")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

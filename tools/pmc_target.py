@@ -16,14 +16,14 @@ dcur = e.to_device(cur); dcnt = e.dev_alloc(L * 4)
 for _ in range(10):
     e.db_match_counts_dev(dcur, Q, dcnt)
 e.sync()
-# the few-query scan (k_db_scan_rows, lane = teach row) on the 100 000-record database of roofline_small_q, Q = 1 and Q = 8
+# the few-query scan (k_db_scan_rows, lane = teach row) on the 100 000-record database of roofline_small_q, Q = 1, 8 and 32
 L2 = 100000
 db2 = rng.integers(0, 256, (L2 * n, 32), dtype=np.uint8)
 off2 = np.arange(L2 + 1, dtype=np.int64) * n
 e2 = Engine(0, 640, 480, 2048)
 e2.db_upload(db2, np.zeros((L2 * n, 3), np.float32), off2, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L2, 1)))
 dcnt2 = e2.dev_alloc(L2 * 4)
-for Q2 in (1, 8):
+for Q2 in (1, 8, 32):
     dq = e2.to_device(cur[:Q2])
     for _ in range(6):
         e2.db_match_counts_dev(dq, Q2, dcnt2)
