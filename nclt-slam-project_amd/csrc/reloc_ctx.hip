@@ -153,7 +153,6 @@ RELOC_API reloc_ctx *reloc_create(int device, int max_w, int max_h, int max_feat
         if (const char *e = getenv("RELOC_SCAN_BATCH_GENS")) c->scan_batch_gens = atoi(e);
         if (const char *e = getenv("RELOC_SCAN_QUOTA_ROWS")) c->scan_quota_rows = atoi(e);
         if (const char *e = getenv("RELOC_LOCAL_TWO_STAGE")) c->local_two_stage = atoi(e) != 0;
-        if (const char *e = getenv("RELOC_FAST_GRID")) c->fast_grid = atoi(e);
     }
     if (ctx_alloc(c) != 0) {
         reloc_destroy(c);

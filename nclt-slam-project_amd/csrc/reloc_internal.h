@@ -54,9 +54,21 @@ constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps t
 // phase stretches 2-3x (k_pyramid 49 vs 17 us, k_fast_blur 46 vs 16) and the scans of the streams overlap less.  With
 // priority the same instructions are issued, only sooner: 4-stream run 6060 -> 6250 frames/s, single-stream ticks unchanged.
 // -DRELOC_SMALL_PRIO=0 switches it off (A/B builds).
-// Workgroups of the FAST + blur launch of a tick that shares the chip with scans (orb_fast_grid in reloc_orb.hip); -1 = one per tile.
-#ifndef RELOC_FAST_GRID_SHARED
-#define RELOC_FAST_GRID_SHARED 512
+// Register budget of the scan kernels (k_db_scan, k_db_scan_batch), capped with amdgpu_num_vgpr (0 = the compiler's choice: 112).
+// Four scan waves per SIMD at 112 registers leave 64 of the 512 per lane to whatever else wants to run beside them -- and
+// k_pyramid (94), k_pnp_hyp (94), k_tick_finalize (80) do not fit into 64: they wait for a scan workgroup to retire.  At 104
+// (28 bytes of scratch) four scan waves leave 96 and a fifth still does not fit (5 x 104 > 512); at 96 a fifth does, and
+// nothing else any more.  4-stream run, interleaved on one box (profiles/r4_scan_vgpr.log): 112 / 104 / 96 registers = 6 648 /
+// 6 716 / 6 560 frames/s, synchronous whole-database tick 273 / 269 / 280 us.  (Cutting k_pnp_finish and the emit pass to 96 registers so
+// that they fit beside the scans as well changes nothing: 6 747-6 760 vs 6 753 frames/s, same log.)
+#ifndef RELOC_SCAN_NUM_VGPR
+#define RELOC_SCAN_NUM_VGPR 104
+#endif
+#if RELOC_SCAN_NUM_VGPR > 0
+// (the backend doubles the attribute's value on targets with the unified VGPR / AGPR file: half of the wanted count is passed)
+#define RELOC_SCAN_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RELOC_SCAN_NUM_VGPR / 2)))
+#else
+#define RELOC_SCAN_VGPR_ATTR
 #endif
 #ifndef RELOC_SMALL_PRIO
 #define RELOC_SMALL_PRIO 3
@@ -273,7 +285,6 @@ struct reloc_ctx {
     int scan_gens = 0;               // RELOC_SCAN_GENS (developer switch): generations of the ticket grid, < 0 = one, no quota
     int scan_batch_gens = 0;         // RELOC_SCAN_BATCH_GENS (developer switch): generations of a batched scan launch
     int scan_quota_rows = 1;         // RELOC_SCAN_QUOTA_ROWS (developer switch): 1 = workgroup budgets in rows + sweepers, 0 = a quota of records (rounds 2-3a)
-    int fast_grid = 0;               // RELOC_FAST_GRID (developer switch): workgroups of k_fast_blur, 0 = by context (orb_fast_grid)
     int scan_nw = 0;                 // RELOC_SCAN_NW (developer switch): waves per record of the whole-database scan (1, 2, 4); 0 = by shape
     uint32_t *scan_ticket = nullptr; // per frame of a batch (<= 8) 8 per-XCD record counters, then 1 exit counter, 128 bytes apart
 

@@ -621,7 +621,7 @@ __device__ __forceinline__ void db_count_body(
 // its feature capacity and always runs NJ = 8.  (One kernel branching on the device-side count was measured:
 // it costs the NJ = 8 path 3 %.)
 template <int NJ, bool EMIT, int NW>
-__global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) void k_db_scan(
+__global__ __launch_bounds__(64 * NW, NW >= 4 ? 16 / NW : 4) RELOC_SCAN_VGPR_ATTR void k_db_scan(
     const uint4 *__restrict__ db, const int64_t *__restrict__ off, const int32_t *__restrict__ rec_ids,
     const int32_t *__restrict__ n_ids_p, int n_ids_max, const uint4 *__restrict__ cur,
     const int32_t *__restrict__ n_cur_p, int n_cur_max, int max_rows, int32_t *__restrict__ counts,
@@ -645,7 +645,7 @@ struct EmitFrame {
 };
 struct EmitBatch { EmitFrame f[RELOC_BATCH_MAX]; };
 
-__global__ __launch_bounds__(256, 4) void k_db_emit_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids_max,
+__global__ __launch_bounds__(256, 4) RELOC_SCAN_VGPR_ATTR void k_db_emit_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids_max,
                                                           int n_cur_max, int max_rows, int emit_stride, const float *__restrict__ g_pts3d,
                                                           EmitBatch bt)
 {
@@ -699,7 +699,7 @@ struct ScanBatch {
     double cos_tol;
 };
 
-__global__ __launch_bounds__(256, 4) void k_db_scan_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids,
+__global__ __launch_bounds__(256, 4) RELOC_SCAN_VGPR_ATTR void k_db_scan_batch(const uint4 *__restrict__ db, const int64_t *__restrict__ off, int n_ids,
                                                           int n_cur_max, int max_rows, ScanBatch bt, u32 *ticket_pool, int quota, int n_bounded, int col_words)
 {
     extern __shared__ u32 lds[];

@@ -535,39 +535,24 @@ __device__ float harris_px(const uint8_t *p, int step)
     return __fmul_rn(t7, s4);
 }
 
-// FAST + NMS tiles and 7x7 blur tiles of all levels in ONE launch: both only read the pyramid, FAST feeds
-// Harris and the blur feeds the descriptors, so they need not run one after the other.
+// FAST + NMS tiles and 7x7 blur tiles of all levels in ONE launch, one workgroup per tile: both only read the pyramid, FAST
+// feeds Harris and the blur feeds the descriptors, so they need not run one after the other.  (A smaller grid whose workgroups
+// walk the tiles paid beside 112-register scans and pays nothing beside 104-register ones: profiles/README.md "Dropped
+// experiments" #8.)
 __global__ __launch_bounds__(256) void k_fast_blur(const OrbTable *__restrict__ tab, const uint8_t *__restrict__ pyr,
                                                    uint8_t *__restrict__ nms, int32_t *__restrict__ hist,
-                                                   uint8_t *__restrict__ blur, int n_fast, int n_tiles)
+                                                   uint8_t *__restrict__ blur, int n_fast)
 {
     RELOC_SMALL_KERNEL_PRIO();
-    // one workgroup per tile, or (n_tiles > gridDim.x) a smaller grid of workgroups that walk the tiles -- see orb_fast_grid().
-    // The tile functions leave LDS in a state the next tile may overwrite: every array's last readers sit in front of a barrier
-    // that the next tile's first writers of that array come behind.
-    for (int t = (int)blockIdx.x; t < n_tiles; t += (int)gridDim.x) {
-        if (t < n_fast) fast_nms_tile(tab, pyr, nms, hist, t);
-        else blur7_tile(tab, pyr, blur, t - n_fast);
-    }
+    if ((int)blockIdx.x < n_fast) fast_nms_tile(tab, pyr, nms, hist, (int)blockIdx.x);
+    else blur7_tile(tab, pyr, blur, (int)blockIdx.x - n_fast);
 }
-__global__ __launch_bounds__(256) void k_fast_blur_batch(OrbBatch b, int n_fast, int n_tiles)
+__global__ __launch_bounds__(256) void k_fast_blur_batch(OrbBatch b, int n_fast)
 {
     RELOC_SMALL_KERNEL_PRIO();
     const OrbFrame &F = b.f[blockIdx.y];
-    for (int t = (int)blockIdx.x; t < n_tiles; t += (int)gridDim.x) {
-        if (t < n_fast) fast_nms_tile(F.tab, F.pyr, F.nms, F.hist, t);
-        else blur7_tile(F.tab, F.pyr, F.blur, t - n_fast);
-    }
-}
-
-// Workgroups of the FAST + blur launch: one per tile (~2 000 at 640x480) where the tick has the chip to itself; beside other
-// streams' whole-database scans those workgroups queue for the few wave slots the scans leave free, one dispatch each, and the
-// kernel lasts 2.3x its unloaded time (round 3) -- there a smaller grid whose workgroups keep their slot and walk the tiles.
-static int orb_fast_grid(const reloc_ctx *ctx, int n_tiles, bool latency_shape)
-{
-    int g = ctx->fast_grid;                                       // RELOC_FAST_GRID (developer switch): > 0 workgroups, < 0 one per tile
-    if (g == 0) g = latency_shape ? -1 : RELOC_FAST_GRID_SHARED;
-    return g < 0 || g > n_tiles ? n_tiles : g;
+    if ((int)blockIdx.x < n_fast) fast_nms_tile(F.tab, F.pyr, F.nms, F.hist, (int)blockIdx.x);
+    else blur7_tile(F.tab, F.pyr, F.blur, (int)blockIdx.x - n_fast);
 }
 
 
@@ -1113,9 +1098,8 @@ int orb_run_dev(reloc_ctx *ctx, const uint8_t *src_dev, int w, int h, int stride
         hipLaunchKernelGGL(wide ? kern512 : kern256, dim3(ctx->pyr_ntiles), dim3(wide ? 512 : 256), ctx->pyr_lds_bytes, st, tab_d,
                            (const PyrTile *)ctx->pyr_tiles, ctx->rz_tab, src_dev, w, h, stride, gray_flags(ctx, order), ctx->pyr, lds, ctx->hist, ctx->cand_cnt);
     }
-    const int n_fb_tiles = tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV];
-    hipLaunchKernelGGL(k_fast_blur, dim3(orb_fast_grid(ctx, n_fb_tiles, ctx->orb_latency_shape)), dim3(256), 0, st, tab_d, ctx->pyr,
-                       ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV], n_fb_tiles);
+    hipLaunchKernelGGL(k_fast_blur, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr,
+                       ctx->nms, ctx->hist, ctx->blur, tab_h->fast_tile_base[NLEV]);
     hipLaunchKernelGGL(k_harris, dim3(tab_h->flat_base[NLEV]), dim3(256), 0, st, tab_d, ctx->pyr, ctx->nms, ctx->hist,
                        ctx->cand_cnt, ctx->cand_key, ctx->cand_resp, ctx->dbg_cut);
     hipLaunchKernelGGL(k_select, dim3(NLEV), dim3(1024), 0, st, tab_d, ctx->cand_cnt,
@@ -1165,10 +1149,8 @@ int orb_run_batch_dev(reloc_ctx *const *ctxs, int n, const uint8_t *const *srcs_
         hipLaunchKernelGGL((k_pyramid_batch<3, true, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, gray_flags(c0, order), lds);
     else
         hipLaunchKernelGGL((k_pyramid_batch<3, false, 256>), dim3(c0->pyr_ntiles, n), dim3(256), c0->pyr_lds_bytes, st, b, w, h, stride, gray_flags(c0, order), lds);
-    const int n_fb_tiles = tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV];
-    int fb_grid = orb_fast_grid(c0, n_fb_tiles, false);
-    if (fb_grid < n_fb_tiles) fb_grid = (fb_grid + n - 1) / n < 64 ? 64 : (fb_grid + n - 1) / n;      // the budget is the launch's, not a frame's
-    hipLaunchKernelGGL(k_fast_blur_batch, dim3(fb_grid, n), dim3(256), 0, st, b, tab_h->fast_tile_base[NLEV], n_fb_tiles);
+    hipLaunchKernelGGL(k_fast_blur_batch, dim3(tab_h->fast_tile_base[NLEV] + tab_h->blur_tile_base[NLEV], n), dim3(256), 0, st, b,
+                       tab_h->fast_tile_base[NLEV]);
     hipLaunchKernelGGL(k_harris_batch, dim3(tab_h->flat_base[NLEV], n), dim3(256), 0, st, b);
     hipLaunchKernelGGL(k_select_batch, dim3(NLEV, n), dim3(1024), 0, st, b);
     hipLaunchKernelGGL(k_describe_batch, dim3((c0->max_feat + 3) / 4, n), dim3(256), 0, st, b, c0->max_feat);

@@ -15,6 +15,7 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/sq -o sq -- python3 tools/pmc_target.py > $P/sq.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_SALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $P/sq2 -o sq2 -- python3 tools/pmc_target.py > $P/sq2.log 2>&1
 python tools/pmc_summarize.py $P $P/summary.json > /dev/null || true
+mkdir -p profiles/pmc_$R && cp $P/summary.json profiles/pmc_$R/summary.json      # bench.py reads the round's own traffic figures
 echo pmc done
 timeout -k 10 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 echo bench done
@@ -40,7 +41,11 @@ timeout -k 10 400 python bench.py --shard-db --records 100000 --steps 10 2>/dev/
 timeout -k 10 300 python bench.py --shard-db --steps 30 2>/dev/null | tail -1 > $O/bench_shard10k.json || true
 timeout -k 10 300 python bench.py --matrix-only --steps 200 2>/dev/null | tail -1 > $O/bench_matrix_only.json || true
 # the multi-rank code paths with two ranks on this ONE GPU (gloo; not a scaling number)
-timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --backend gloo --rehearse --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_rehearsal.json || true
+timeout -k 10 200 python bench.py --gpus 2 --steps 10 --warmup 2 --backend gloo --rehearse --no-matrix $NOX 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_rehearsal.json || true
+# the RCCL transport at world size 1 (one rank, one GPU): both exchanges of the sharded path and the frame benchmark's barrier / all_reduce
+timeout -k 10 300 python bench.py --shard-db --force-dist --steps 30 2>/dev/null | tail -1 > $O/bench_shard10k_rccl_world1.json || true
+timeout -k 10 200 python tools/exp_maxfeat_scan.py > $O/scan_maxfeat.log 2>&1 || true
+timeout -k 10 300 python tools/exp_small_q.py nclt-slam-project_amd/csrc/libreloc_hip.so > $O/small_q.log 2>/dev/null || true
 echo extra done
 fi
 echo collected
