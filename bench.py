@@ -213,9 +213,9 @@ def pmc_traffic(kernel):
 def scan_case(e, L, rows, Qs, seed, forms=(False, True), n=40, preroll=30):
     """The whole-database mutual-match scan alone on one stream (reloc_db_match_counts_dev), HIP events around the kernel:
     one roofline object per (Q, scheduling form).  Q <= 64 runs the lane-per-teach-row kernel k_db_scan_rows (HBM-bound, no
-    scheduling forms); larger Q the column-per-lane kernel k_db_scan in its two forms: `shared` = generations of workgroups
-    with a record quota (what a context runs beside other streams: the timed 4-stream region) and `alone` = one resident
-    generation (reloc_set_exclusive, and the default of a process's only context)."""
+    scheduling forms); larger Q the column-per-lane kernel k_db_scan, timed with the context marked `shared` and `alone`
+    (reloc_set_exclusive).  Since round 4 a single launch runs ONE resident generation of workgroups in both (rounds 2-3: three
+    generations with budgets when shared), so the two figures differ by run-to-run noise only; both are kept for continuity."""
     from nclt_slam_project_amd import synth
     rng = np.random.default_rng(seed)
     desc, pts, off, poses = synth.descriptor_db(rng, L, rows)

@@ -70,6 +70,16 @@ constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps t
 #else
 #define RELOC_SCAN_VGPR_ATTR
 #endif
+// Scheduling form of the whole-database scan in a context that shares the chip: n > 0 = n generations of workgroups, each with
+// a row budget, sweepers behind them; 0 = ONE resident generation that draws records until the counters are dry (what a lone
+// context has always run).  Rounds 2-3: three generations, so that other streams' small kernels found slots when a generation
+// retired.  Since the scan leaves them 96 registers they run BESIDE resident scans: 4 streams, interleaved on one box
+// (profiles/r4_scan_generations.log), 1 / 2 / 3 / 4 generations 6 853 / 6 759 / 6 752 / 6 604 frames/s, one generation without
+// budgets 6 826 -- and that form scans in 152 us on an idle chip where one generation WITH budgets takes 177 (static shares
+// leave a tail).  A batched launch (k_db_scan_batch) keeps one generation of budgets per frame.
+#ifndef RELOC_SCAN_GENS_SHARED
+#define RELOC_SCAN_GENS_SHARED 0
+#endif
 #ifndef RELOC_SMALL_PRIO
 #define RELOC_SMALL_PRIO 3
 #endif

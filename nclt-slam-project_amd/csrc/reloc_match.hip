@@ -1104,7 +1104,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     int quota = 0, n_bounded = 0;
     if (!rec_ids && !n_ids_dev && n_ids_max > resident && ctx->scan_ticket && ctx->scan_grid >= 0 && nj == 8) {
         ticket = ctx->scan_ticket;
-        const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : 3;
+        const int gens = ctx->scan_gens > 0 ? ctx->scan_gens : (RELOC_SCAN_GENS_SHARED > 0 ? RELOC_SCAN_GENS_SHARED : 1);
         // `gens` generations of workgroups: all but the last resident one leave after their share of the database's ROWS, the
         // last generation draws until the counters are dry (see db_count_body); the row total is the host's when the
         // context's own database is scanned, else 64 per record
@@ -1115,7 +1115,9 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
         quota = (int)((rows * q_rec + n_ids_max - 1) / n_ids_max);                        // that many records' worth of ROWS
         if (quota < 1) quota = 1;
         if (!ctx->scan_quota_rows) { quota = q_rec; grid = n_bounded; n_bounded = -1; }   // developer switch: the record quota of rounds 2-3a
-        if (ctx_alone(ctx) && ctx->scan_gens == 0) { quota = 0; grid = resident; }     // reloc_set_exclusive: one generation, nobody to hand slots to
+        // ONE resident generation that draws until the counters are dry: always for a context that is alone (reloc_set_exclusive:
+        // nobody to hand slots to), and since round 4 beside other streams as well (RELOC_SCAN_GENS_SHARED == 0, reloc_internal.h)
+        if ((ctx_alone(ctx) || RELOC_SCAN_GENS_SHARED == 0) && ctx->scan_gens == 0) { quota = 0; grid = resident; }
         if (ctx->scan_gens < 0) { quota = 0; grid = ctx->scan_gens <= -2 ? ctx->num_cu * (-ctx->scan_gens - 1) : resident; }   // developer switch: one generation, no quota; -2 / -3 / -4: 1 / 2 / 3 workgroups per CU
     }
     if (grid > n_ids_max) grid = n_ids_max;
@@ -1166,7 +1168,7 @@ int launch_db_scan_batch(reloc_ctx *const *ctxs, int n, const double *q, double 
     const int ncb = (c0->max_feat + 511) / 512;
     const int col_words = (ncb >= 2 ? ncb : 2) * 512;         // see launch_db_scan
     const size_t lds_all = (size_t)(col_words + max_rows + 16) * 4;
-    int gens = c0->scan_gens > 0 ? c0->scan_gens : 3;
+    int gens = c0->scan_gens > 0 ? c0->scan_gens : (RELOC_SCAN_GENS_SHARED > 0 ? RELOC_SCAN_GENS_SHARED : 1);
     if (c0->scan_batch_gens > 0) gens = c0->scan_batch_gens;
     const int resident = c0->num_cu * 4;
     // the grid holds `gens` generations in all (not per frame): a workgroup's quota grows with the batch, and with it

@@ -16,6 +16,11 @@ ap.add_argument("--kinds", default="", help="comma-separated subset of the case 
 args = ap.parse_args()
 O.build()
 e = Engine(0, 1280, 720, 8192)
+# a second context in the generations form of the whole-database scan (row budgets + sweepers: the default of batched launches;
+# single launches use one resident generation since round 4): developer switches are read at creation, under RELOC_DEV=1
+os.environ["RELOC_DEV"] = "1"; os.environ["RELOC_SCAN_GENS"] = "3"
+e_gens = Engine(0, 1280, 720, 8192)
+del os.environ["RELOC_DEV"], os.environ["RELOC_SCAN_GENS"]
 rng = np.random.default_rng(args.seed)
 t_end = time.time() + args.seconds
 n_case = {"match": 0, "knn": 0, "db": 0, "db_small": 0, "db_big": 0, "ratio": 0, "matrix": 0, "orb": 0, "orb_bgr": 0, "pnp": 0, "record": 0}
@@ -85,12 +90,10 @@ while time.time() < t_end:
         n = rng.integers(0, 24, L); n[rng.choice(L, 5, replace=False)] = rng.integers(100, 900, 5)
         off = np.zeros(L + 1, np.int64); off[1:] = np.cumsum(n)
         cur = descs(Q); db = descs(max(int(off[-1]), 1))[: int(off[-1])]
-        e.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
         x = O.db_match_counts(db, off, cur)
-        for form in (False, True):
-            e.set_exclusive(form)
-            g = e.db_match_counts(cur)
-            e.set_exclusive(None)
+        for form, eng in (("one", e), ("gens3", e_gens)):
+            eng.db_upload(db, np.zeros((len(db), 3), np.float32), off, np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1)))
+            g = eng.db_match_counts(cur)
             if not np.array_equal(g, x): fail(kind, (L, Q, form, int((g != x).sum())))
     elif kind == "matrix":
         na, nb = int(rng.integers(1, 300)), int(rng.integers(1, 5000))

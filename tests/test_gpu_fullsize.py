@@ -40,10 +40,12 @@ def test_db_scan_10k_records(engine, oracle):
 
 
 @pytest.mark.parametrize("rows", ["ragged", "fixed64", 7, "spiky"])
-def test_db_scan_scheduling_forms_agree_on_every_record(engine, rows):
-    """the whole-database scan in the generations form (workgroups with a row budget + sweepers: what a context runs beside
-    other streams) and in the one-generation form (reloc_set_exclusive) must write the SAME count for EVERY record -- a ticket
-    that no workgroup served would leave a stale count -- on ragged, uniform, tiny and very uneven record sizes"""
+def test_db_scan_scheduling_forms_agree_on_every_record(engine, rows, monkeypatch):
+    """the whole-database scan in the generations form (workgroups with a row budget + sweepers: what batched launches use, and
+    single launches under the developer switch RELOC_SCAN_GENS) and in the one-generation form (the default since round 4) must
+    write the SAME count for EVERY record -- a ticket that no workgroup served would leave a stale count -- on ragged, uniform,
+    tiny and very uneven record sizes"""
+    from nclt_slam_project_amd.engine import Engine
     rng = np.random.default_rng(31)
     cur = synth.random_descriptors(rng, 500)
     L = 6000
@@ -54,26 +56,33 @@ def test_db_scan_scheduling_forms_agree_on_every_record(engine, rows):
         poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (L, 1))
     else:
         desc, pts, off, poses = synth.descriptor_db(rng, L, rows, cur, planted_records=(5, 3000, L - 1))
-    engine.db_upload(desc, pts, off, poses)
-    dcur = engine.to_device(cur)
     out = {}
-    try:
-        for form in (True, False, True):
-            engine.set_exclusive(form)
-            cnt = engine.dev_alloc(L * 4)
-            engine.h2d(cnt, np.full(L, -7, np.int32))              # poison: an unserved record keeps it
-            engine.db_match_counts_dev(dcur, 500, cnt)
+    for form, gens in (("one", None), ("gens3", "3"), ("gens1", "1")):
+        if gens is None:
+            e = engine
+        else:                       # developer switches are read at reloc_create, under RELOC_DEV=1
+            monkeypatch.setenv("RELOC_DEV", "1"); monkeypatch.setenv("RELOC_SCAN_GENS", gens)
+            e = Engine(0, 640, 480, 2048)
+            monkeypatch.delenv("RELOC_DEV"); monkeypatch.delenv("RELOC_SCAN_GENS")
+        e.db_upload(desc, pts, off, poses)
+        dcur = e.to_device(cur)
+        for rep in range(2):
+            cnt = e.dev_alloc(L * 4)
+            e.h2d(cnt, np.full(L, -7, np.int32))                   # poison: an unserved record keeps it
+            e.db_match_counts_dev(dcur, 500, cnt)
             got = np.empty(L, np.int32)
-            engine.d2h(got, cnt)
-            engine.dev_free(cnt)
+            e.d2h(got, cnt)
+            e.dev_free(cnt)
             out.setdefault(form, []).append(got)
-    finally:
-        engine.set_exclusive(None)
-        engine.dev_free(dcur)
-    assert (out[False][0] >= 0).all(), "a record was never scored"
-    np.testing.assert_array_equal(out[False][0], out[True][0])
-    np.testing.assert_array_equal(out[True][1], out[True][0])
-    assert (out[True][0] <= np.minimum(np.diff(off), 500)).all()
+        e.dev_free(dcur)
+        if gens is not None:
+            e.close()
+    assert (out["one"][0] >= 0).all(), "a record was never scored"
+    for form in ("gens3", "gens1"):
+        np.testing.assert_array_equal(out[form][0], out["one"][0])
+        np.testing.assert_array_equal(out[form][1], out["one"][0])  # the ticket counters were put back
+    np.testing.assert_array_equal(out["one"][1], out["one"][0])
+    assert (out["one"][0] <= np.minimum(np.diff(off), 500)).all()
 
 
 def test_hamming_matrix_20k(engine):

@@ -20,9 +20,9 @@ echo pmc done
 timeout -k 10 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 echo bench done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 10 --warmup 2 $NOX > $O/stats.log 2>&1
-# one stream, but the scan in the SAME scheduling form as the 4-stream line's `roofline` (generations with budgets; a process's only
-# context would otherwise take the one-generation form, ~10 us faster): the kernel's average here is what roofline.avg_launch_us states
-RELOC_DEV=1 RELOC_SCAN_GENS=3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-matrix $NOX > $O/stats1.log 2>&1
+# one stream: the scan in the scheduling form of the 4-stream line's `roofline` (one resident generation since round 4, in every
+# context): the kernel's average here is what roofline.avg_launch_us states
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o bench1 -- python3 bench.py --streams 1 --steps 10 --warmup 2 --no-matrix $NOX > $O/stats1.log 2>&1
 # the matrix kernel: trace of bench.py --matrix-only (400 pre-roll + 1 warm-up + 100 timed launches), statistics of the TIMED tail only
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/mtrace -o matrix -- python3 bench.py --matrix-only --steps 100 --warmup 1 > $O/matrix_trace_bench.json 2>$O/mtrace.err
 python tools/kernel_trace_tail.py $O/mtrace k_hamming_matrix 100 > $O/matrix_timed_only.json || true
