@@ -60,7 +60,8 @@ constexpr int64_t MAX_DB_RECORDS = 0xFFFFF;   // the local-candidate key keeps t
 // (28 bytes of scratch) four scan waves leave 96 and a fifth still does not fit (5 x 104 > 512); at 96 a fifth does, and
 // nothing else any more.  4-stream run, interleaved on one box (profiles/r4_scan_vgpr.log): 112 / 104 / 96 registers = 6 648 /
 // 6 716 / 6 560 frames/s, synchronous whole-database tick 273 / 269 / 280 us.  (Cutting k_pnp_finish and the emit pass to 96 registers so
-// that they fit beside the scans as well changes nothing: 6 747-6 760 vs 6 753 frames/s, same log.)
+// that they fit beside the scans as well: nothing with three scan generations, 6 747-6 760 vs 6 753 frames/s; with the one generation of
+// today 4-7 % WORSE, 6 320-6 550 vs 6 822 -- they are better off in the gap between two scans than competing with one; same log.)
 #ifndef RELOC_SCAN_NUM_VGPR
 #define RELOC_SCAN_NUM_VGPR 104
 #endif

@@ -1061,6 +1061,10 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     if (max_rows < 1) max_rows = 1;
     if (!m_qidx && !rec_ids && !n_ids_dev && !mask.xyh && counts && n_cur_max <= 64 && max_rows <= SQ_MAX_ROWS) {
         // few queries: lane = teach row (k_db_scan_rows)
+        if (n_cur_max == 0) {                              // a capacity of zero descriptors: nothing may be read from `cur`
+            HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_ids_max * sizeof(int32_t), ctx->stream));
+            return RELOC_OK;
+        }
         int grid = ctx->num_cu * 8;                        // 8 workgroups of 4 waves per CU
         const int need = (n_ids_max + SQ_WAVES - 1) / SQ_WAVES;
         if (grid > need) grid = need;

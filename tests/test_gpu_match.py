@@ -139,8 +139,9 @@ def test_few_query_scan_every_query_count(engine, oracle, low_entropy):
     cur_dev = engine.to_device(cur)
     cnt_dev = engine.dev_alloc(L * 4)
     ncur_dev = engine.dev_alloc(4)
-    for cap, real in ((64, 5), (64, 17), (64, 33), (8, 3), (4, 1), (64, 0)):
+    for cap, real in ((64, 5), (64, 17), (64, 33), (8, 3), (4, 1), (64, 0), (0, 0)):
         engine.h2d(ncur_dev, np.array([real], np.int32))
+        engine.h2d(cnt_dev, np.full(L, -3, np.int32))                   # poison: every record's count must be written
         engine.db_match_counts_dev(cur_dev, cap, cnt_dev, ncur_dev)
         engine.sync()
         got = np.empty(L, np.int32); engine.d2h(got, cnt_dev)
