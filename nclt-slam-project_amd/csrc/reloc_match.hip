@@ -125,6 +125,10 @@ __device__ __forceinline__ void ham8_cols(const u32 (&q)[NC][8], const u32 (&w)[
 __device__ __forceinline__ void srow_landed(u32 first_dword) { asm volatile("" ::"s"(first_dword)); }
 
 __device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 __device__ __forceinline__ u32 umax(u32 a, u32 b) { return a > b ? a : b; }
 
 // One butterfly exchange: on entry a = vector i, b = vector i+K on every lane.  On exit the
@@ -522,6 +526,9 @@ __device__ __forceinline__ void db_count_body(
     if (mask.xyh) {
         cur_heading_q(mask.q, hc, hs);
         cos_tol = mask.cos_tol;
+        // wave-uniform values computed on the vector unit: moved to scalar registers (they live across the whole launch, and
+        // the kernel is capped at 104 vector registers)
+        hc = uniform_f64(hc); hs = uniform_f64(hs); cos_tol = uniform_f64(cos_tol);
     }
     constexpr int TICKET_STRIDE = 32;
     int shard = 0, dry = 0;
