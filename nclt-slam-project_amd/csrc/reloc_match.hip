@@ -150,33 +150,31 @@ __device__ __forceinline__ u32 bfly(u32 a, u32 b, int lane)
     }
 }
 
-// Reduce R vectors (one value per lane each, R = 4, 8 or 16) to one: afterwards lane l holds the
-// minimum over all 64 lanes of vector (l mod R).
-template <int R>
-__device__ __forceinline__ u32 rows_min(u32 (&d)[R], int lane)
+// The same exchange with the lane movement IN the minimum (v_min_u32 with a DPP operand) for the lane bits where a bank mask
+// can tell the two halves apart: bit 2 (K = 4: row_shl:4 on banks 0 / 2 serves the lanes that keep vector a, row_shr:4 on banks
+// 1 / 3 those that keep b -- a lane needs only ITS vector's partner) and bit 3 (K = 8: row_ror:8, banks 0-1 / 2-3).  Two
+// instructions instead of two selects, a DPP move and a minimum.  Inline asm: the s_nop covers the two wait states a DPP read
+// needs after a VALU write of its source, which the compiler does not count for an asm statement.
+template <int K>
+__device__ __forceinline__ u32 bfly_dpp(u32 a, u32 b)
 {
-    if constexpr (R >= 16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = bfly<8>(d[i], d[i + 8], lane);
-    }
-    if constexpr (R >= 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = bfly<4>(d[i], d[i + 4], lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) d[i] = bfly<2>(d[i], d[i + 2], lane);
-    u32 x = bfly<1>(d[0], d[1], lane);
-    if constexpr (R <= 4) x = umin(x, dpp_xor<4>(x));
-    if constexpr (R <= 8) x = umin(x, dpp_xor<8>(x));
-    {   // ^16, ^32: after a swap with itself the two results are the lane's value and its partner's
-        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-        x = umin(r[0], r[1]);
-        const auto q = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-        x = umin(q[0], q[1]);
-    }
+    static_assert(K == 4 || K == 8, "bank-maskable lane bits only");
+    u32 r;
+    if constexpr (K == 4)
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_u32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(r) : "v"(a), "v"(b));
+    else
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_u32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc" : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// all-reduce over lane bit 0 / bit 1 (quad_perm exchange in the minimum)
+__device__ __forceinline__ u32 allmin_quad(u32 x)
+{
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
     return x;
 }
-
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
 template <class F, int... I>
@@ -201,7 +199,7 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
     u32 cb16[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) cb16[j] = 0xFFFFu;
-    // The R row keys are reduced by the register-tile butterfly of rows_min<R>, but AS THEY COME: the rows of the chunk
+    // The R row keys are reduced by a register-tile butterfly, but AS THEY COME: the rows of the chunk
     // are visited in bit-reversed order (0, R/2, R/4, 3R/4, ...), so the two operands of every butterfly node are
     // finished right after each other and at most log2(R) + 1 partial results are alive instead of R keys -- 11
     // VGPRs less at R = 16, which takes the kernel from 115 to <= 104 registers: four resident workgroups then leave
@@ -235,19 +233,32 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
             }
         }
         u32 v = (best << 9) | (u32)lane;
+        // Node of level k joins rows t and t + R / 2^(k+1).  The four levels split on lane bits 2, 3 (DPP minima, two instructions
+        // a node: the levels with 8 and 4 nodes), 4 and 5 (permlane swap + minimum), and the two lane bits left over are reduced
+        // on the one value at the end: 32 instead of ~66 instructions per chunk and no select masks to keep (rounds 1-3: levels on
+        // bits 3, 2, 1, 0 with select nodes -- two v_cndmask, a DPP move and a minimum each).  4-stream run +1.8 % (6 836 -> 6 958
+        // frames/s, interleaved), and the kernel fits its 104 registers without scratch.  Lane l ends with row 8 b2 + 4 b3 + 2 b4 + b5.
+        static_assert(R == 16, "the level -> lane bit assignment below is for 16-row chunks");
+        auto node = [&](auto level, u32 lo, u32 hi_) -> u32 {
+            constexpr int k = decltype(level)::value;
+            if constexpr (k == 0) return bfly_dpp<4>(lo, hi_);
+            else if constexpr (k == 1) return bfly_dpp<8>(lo, hi_);
+            else if constexpr (k == 2) return bfly<16>(lo, hi_, lane);
+            else return bfly<32>(lo, hi_, lane);
+        };
         if constexpr ((i & 1) == 0) stk[0] = v;
         else {
-            v = bfly<R / 2>(stk[0], v, lane);
+            v = node(std::integral_constant<int, 0>{}, stk[0], v);
             if constexpr ((i & 2) == 0 || LOG_R < 2) stk[1] = v;
             else {
-                v = bfly<R / 4>(stk[1], v, lane);
+                v = node(std::integral_constant<int, 1>{}, stk[1], v);
                 if constexpr (LOG_R >= 3) {
                     if constexpr ((i & 4) == 0) stk[2] = v;
                     else {
-                        v = bfly<R / 8>(stk[2], v, lane);
+                        v = node(std::integral_constant<int, 2>{}, stk[2], v);
                         if constexpr (LOG_R >= 4) {
                             if constexpr ((i & 8) == 0) stk[3] = v;
-                            else stk[4] = bfly<R / 16>(stk[3], v, lane);
+                            else stk[4] = node(std::integral_constant<int, 3>{}, stk[3], v);
                         } else stk[3] = v;
                     }
                 } else stk[2] = v;
@@ -256,17 +267,12 @@ __device__ __forceinline__ void scan_chunk(const uint4 *__restrict__ rec, int n,
         __builtin_amdgcn_sched_barrier(0);
         if (i + 1 < R) { a = na; b = nb; }
     });
-    u32 m = stk[LOG_R];                                               // lane l: minimum over lanes {l, l ^ 1, ..., l ^ (R - 1)} of row l mod R
-    if constexpr (R <= 4) m = umin(m, dpp_xor<4>(m));
-    if constexpr (R <= 8) m = umin(m, dpp_xor<8>(m));
-    {   // ^16, ^32: after a swap with itself the two results are the lane's value and its partner's
-        const auto r16 = __builtin_amdgcn_permlane16_swap(m, m, false, false);
-        m = umin(r16[0], r16[1]);
-        const auto r32 = __builtin_amdgcn_permlane32_swap(m, m, false, false);
-        m = umin(r32[0], r32[1]);
-    }
-    const int row = tc + (lane & (R - 1));
-    if (lane < (FLEX ? nr : R)) {
+    // lane bits 0, 1: every lane now holds the minimum of ITS row; one lane per row writes
+    const u32 m = allmin_quad(stk[LOG_R]);
+    const int row_in_chunk = ((lane >> 2) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane >> 5);
+    const bool writer = (lane & 3) == 0;
+    const int row = tc + row_in_chunk;
+    if (writer && row_in_chunk < (FLEX ? nr : R)) {
         const u32 key = (m & 0xFFFF0000u) | (colbase + ((m >> 9) & 7u) * 64u + (m & 63u));   // distance << 16 | column
         if (single_cb) rowkey[row] = key;
         else atomicMin(&rowkey[row], key);
