@@ -723,9 +723,7 @@ def main(argv=None):
         roofline = dict(kernel="k_db_scan" if NB == 1 else "k_db_scan_batch", frames_per_launch=NB, bound="hbm", achieved=alg_bytes / scan_s / 1e9, peak=8000.0, unit="GB/s",
                         frac=alg_bytes / scan_s / 1e9 / 8000.0, traffic=(pmc_traffic("k_db_scan") or 0) * NB or None,
                         avg_launch_us=scan_s * 1e6, launches=scan_n, algorithmic_bytes=alg_bytes,
-                        note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %; traffic (PMC, "
-                             "profiles/pmc_r4) = 20.5 MB of database + ~8 MB of scratch: the scan is capped at 104 registers so that other "
-                             "kernels fit beside it (28 bytes per lane spilled, served by L2)",
+                        note="VALU-bound by construction: 250 int-op/B at Q=500 (SURVEY.md 8d); HBM fraction cannot exceed ~2 %",
                         valu=dict(pairs_per_s=pairs / scan_s, peak_pairs_per_s=valu_peak_pairs,
                                   frac=pairs / scan_s / valu_peak_pairs,
                                   lane_ops_per_s=16.0 * pairs / scan_s, spec_lane_ops_per_s=78.6e12,
