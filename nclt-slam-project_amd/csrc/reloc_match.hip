@@ -1110,7 +1110,7 @@ int launch_db_scan(reloc_ctx *ctx, const uint8_t *db_desc, const int64_t *db_off
     // or 2, or ONE wave owns a record (no row left for a second chunk epilogue, no barrier that waits for anybody).
     int nw = 4;
     if (!m_qidx && nj == 8) {
-        nw = ctx->scan_nw == 1 || ctx->scan_nw == 2 || ctx->scan_nw == 4 ? ctx->scan_nw : 4;
+        nw = ctx->scan_nw == 1 || ctx->scan_nw == 2 || ctx->scan_nw == 4 ? ctx->scan_nw : 4;      // (8: 180 vs 152 us, profiles/r4_scan_intercept.log)
         if (nw == 1 && lds * 16 > 150 * 1024) nw = 2;          // 16 one-wave workgroups per CU have to fit their LDS
     }
     int wg_per_cu = 16 / nw;                       // 16 waves per CU (128-VGPR kernel) ...
