@@ -1,7 +1,7 @@
-"""Developer experiment (rounds 3-4): the few-query scan (k_db_scan_rows / k_db_scan_rows2) of several library builds and / or
-kernel forms (RELOC_SQ_FORM, EXP_FORMS=0,1,2,3) in ONE run, rounds interleaved (boxes of the pool differ by up to 10 %, so only
-same-run comparisons count).  Every form's counts are compared with form 0's (the round-3 kernel, which the test-suite holds
-to the oracle) on every database and query count before it is timed.
+"""Developer experiment (rounds 3-4): the few-query scan (k_db_scan_rows) of several library builds in ONE run, rounds interleaved
+(boxes of the pool differ by up to 10 %, so only same-run comparisons count).  Round 4 also switched kernel forms inside one build
+(EXP_FORMS -> RELOC_SQ_FORM; the switch was removed with the round-3 kernel, profiles/r4_small_q_forms.log): the first build / form
+of a round saves its counts and the others are compared with them on every database and query count before they are timed.
     python tools/exp_small_q.py [lib.so ...]      # default: csrc/libreloc_hip.so + build_variants/*.so
 """
 import glob, json, os, subprocess, sys
