@@ -61,3 +61,23 @@ def test_bare_gpus_2_starts_two_ranks_here():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+def test_force_dist_initialises_a_group_of_one_rank(monkeypatch):
+    """--force-dist: a process group at world size 1 (gloo here; nccl = RCCL on the GPU box, tests/_rccl_world1.py), usable for the
+    barrier and the all_reduce(MAX) of the elapsed time; without the flag a single rank gets no group at all."""
+    import torch
+    for k in ("MASTER_PORT", "MASTER_ADDR", "WORLD_SIZE", "RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.init_dist(argparse.Namespace(force_dist=False, backend="gloo"), torch, 0, 1, 0) is None
+    dist = bench.init_dist(argparse.Namespace(force_dist=True, backend="gloo"), torch, 0, 1, 0)
+    try:
+        assert dist is not None and dist.is_initialized() and dist.get_world_size() == 1
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and 1024 < int(os.environ["MASTER_PORT"]) < 65536
+        dist.barrier()
+        t = torch.tensor([1.25], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.25
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
